@@ -1,0 +1,93 @@
+"""ctypes binding of ``libideas_hip.so`` (C ABI in ``include/ideas_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C ideas_amd/csrc``.  There is NO
+fallback: if the shared object is missing or a symbol is absent, importing an op raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libideas_hip.so")
+
+NCHW, NHWC = 0, 1
+F32 = 0
+
+
+class ConvParams(C.Structure):
+    """Mirror of ``ideas_conv_params`` (include/ideas_hip.h)."""
+    _fields_ = [
+        ("B", C.c_int), ("IH", C.c_int), ("IW", C.c_int), ("Cin", C.c_int),
+        ("YH", C.c_int), ("YW", C.c_int), ("Cout", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int),
+        ("TY", C.c_int), ("TX", C.c_int),
+        ("sy", C.c_int), ("sx", C.c_int), ("dy", C.c_int), ("dx", C.c_int), ("offy", C.c_int), ("offx", C.c_int),
+        ("osy", C.c_int), ("osx", C.c_int), ("ooy", C.c_int), ("oox", C.c_int),
+        ("reflect", C.c_int), ("act", C.c_int),
+        ("alpha", C.c_float), ("act_gain", C.c_float), ("resid_gain", C.c_float),
+        ("accumulate", C.c_int), ("gain", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_PROTOS = {
+    "ideas_abi_version": (C.c_int, []),
+    "ideas_strerror": (C.c_char_p, [C.c_int]),
+    "ideas_fused_bias_act": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                       C.c_float, C.c_float, C.c_int, _P]),
+    "ideas_upfirdn2d": (C.c_int, [_P, _P, _P] + [C.c_int] * 14 + [C.c_float, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_conv_igemm": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
+    "ideas_conv_direct": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
+    "ideas_conv_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
+    "ideas_conv_wgrad_direct": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
+    "ideas_demod": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "ideas_pixel_dot": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
+}
+EXPORTS = tuple(_PROTOS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C ideas_amd/csrc).  ideas_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ideas_abi_version() != 1:
+        raise RuntimeError("libideas_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ideas_strerror(rc).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ideas_amd ops run only on a HIP device tensor (no CPU fallback); got device "
+                               f"{t.device}")

@@ -1,0 +1,29 @@
+// Shared helpers for the gfx950 kernels of libideas_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ideas_hip.h"
+
+#define IDEAS_WAVE 64
+
+static inline int ideas_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? IDEAS_OK : (int)e;
+}
+
+static inline bool ideas_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static inline int64_t ideas_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// mirror an out-of-range coordinate back into [0,n) (ReflectionPad2d semantics, no edge repeat)
+__device__ __forceinline__ int reflect_coord(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}

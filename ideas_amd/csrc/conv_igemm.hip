@@ -1,0 +1,491 @@
+// Implicit-GEMM convolution family on the gfx950 f32 matrix pipe (v_mfma_f32_32x32x2_f32), NHWC.
+//
+// Replaces the cuDNN convolutions of the reference (stylegan2/model.py:115-121 EqualConv2d, :258/:273 the
+// groups=batch modulated convs, models.py:32-38 EqualConvTranspose2d) and their autograd backward.
+//
+//   GEMM view (forward family):  M = B*OH*OW output points, N = Cout, K = TY*TX*Cin, K ordered (ty,tx,ci)
+//   so that with NHWC activations and OHWI weights BOTH operands are contiguous along K: every global access
+//   is a 16-byte vector, no transposes anywhere.
+//
+//   Block = 256 threads = 4 wavefronts, tile BM x BN x 16.  Operands are staged global -> VGPR -> LDS
+//   (register staging, not LDS-DMA: the gather needs per-lane predication for padding / parity phases),
+//   double-buffered so the loads of K-step t+1 fly under the MFMAs of step t; one barrier per K-step.
+//   LDS rows are 16 floats + 4 pad (80 B): ds_read_b128 of 16 consecutive rows then touches 16 distinct
+//   16-byte slots -> conflict-free (MI355X LDS: 64 banks x 4 B, b128 serviced in 16-lane groups).
+//   A wave owns MT x NT tiles of 32x32; lane (i = lane&31, h = lane>>5) reads its 8 consecutive K values
+//   [8h, 8h+8) of row i with two ds_read_b128 and feeds MFMA #kk with element kk — A and B use the same K
+//   permutation, so the sum over (h, kk) covers the 16-wide K-step exactly once.
+//   f32 MFMA is an exact fmaf chain (no TF32-style truncation): results are f32-roundoff class.
+//
+//   The modulated conv never materialises per-sample weights: style s[b,ci] scales the A tile on its way
+//   into LDS and demod d[b,o] scales the accumulator in the epilogue (same contraction, re-associated).
+//
+// Workgroup -> tile mapping is XCD-aware: hardware round-robins consecutive workgroup ids over the 8 XCDs,
+// so ids are remapped to give each XCD (= each private L2) one contiguous band of M tiles with all its N
+// tiles; 3x3 halos and the N-tile re-reads of the same activations then hit that XCD's L2.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;    // K (or pixel) depth of one pipeline step
+constexpr int LDK = 20;   // padded LDS row length (floats) of the K-contiguous tiles
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
+    const int q = nblk >> 3, rem = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// =====================================================================================================
+// forward family
+// =====================================================================================================
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ wmat,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ out_scale,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ resid, ideas_conv_params p,
+                                                            int tiles_n) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    constexpr int A_PER = (BM * 4 + 255) / 256;   // float4 loads per thread for the A tile
+    constexpr int B_PER = (BN * 4 + 255) / 256;
+    constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
+    static_assert(LDS_FLOATS * 4 >= BM * 12, "epilogue row table must fit");
+    __shared__ __attribute__((aligned(16))) float smem[LDS_FLOATS];
+    float* As = smem;                    // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
+
+    const int t = threadIdx.x;
+    const int64_t M = (int64_t)p.B * p.OH * p.OW;
+    const int K = p.TY * p.TX * p.Cin;
+    const int nblk = gridDim.x;
+    const int swz = xcd_swizzle(blockIdx.x, nblk);
+    const int tile_n = swz % tiles_n;
+    const int tile_m = swz / tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- per-thread gather state ---------------------------------------------------------------
+    const int kq = t & 3;  // which float4 of the 16-wide K-step
+    int a_iyb[A_PER], a_ixb[A_PER], a_b[A_PER];
+    bool a_ok[A_PER];
+    int64_t a_base[A_PER];
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int r = (t >> 2) + 64 * j;
+        const int64_t m = m0 + r;
+        a_ok[j] = (r < BM) && (m < M);
+        const int64_t mm = a_ok[j] ? m : 0;
+        const int ox = (int)(mm % p.OW);
+        const int64_t q = mm / p.OW;
+        const int oy = (int)(q % p.OH);
+        const int b = (int)(q / p.OH);
+        a_b[j] = b;
+        a_iyb[j] = oy * p.sy + p.offy;
+        a_ixb[j] = ox * p.sx + p.offx;
+        a_base[j] = (int64_t)b * p.IH * p.IW * p.Cin;
+    }
+    const float* b_ptr[B_PER];
+    bool b_ok[B_PER];
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+        const int r = (t >> 2) + 64 * j;
+        b_ok[j] = (r < BN) && (n0 + r < p.Cout);
+        b_ptr[j] = wmat + (int64_t)(b_ok[j] ? n0 + r : 0) * K + kq * 4;
+    }
+    // tap walker for this thread's K column
+    int k_ci, k_tx, k_ty;
+    {
+        const int k = kq * 4;
+        const int tap = k / p.Cin;
+        k_ci = k - tap * p.Cin;
+        k_ty = tap / p.TX;
+        k_tx = tap - k_ty * p.TX;
+    }
+
+    float4 ra[A_PER], rb[B_PER];
+    auto gload = [&](int kt) {
+        const bool kvalid = k_ty < p.TY;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            int iy = a_iyb[j] + k_ty * p.dy;
+            int ix = a_ixb[j] + k_tx * p.dx;
+            bool ok = a_ok[j] && kvalid;
+            if (p.reflect) {
+                iy = reflect_coord(iy, p.IH);
+                ix = reflect_coord(ix, p.IW);
+            } else {
+                ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(x + a_base[j] + ((int64_t)iy * p.IW + ix) * p.Cin + k_ci);
+                if (in_scale) v = mul4(v, *reinterpret_cast<const float4*>(in_scale + (int64_t)a_b[j] * p.Cin + k_ci));
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_ok[j] && kvalid) v = *reinterpret_cast<const float4*>(b_ptr[j] + (int64_t)kt * BK);
+            rb[j] = v;
+        }
+        // advance the walker by one K-step
+        k_ci += BK;
+        while (k_ci >= p.Cin) {
+            k_ci -= p.Cin;
+            if (++k_tx == p.TX) { k_tx = 0; ++k_ty; }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            const int r = (t >> 2) + 64 * j;
+            if (r < BM) *reinterpret_cast<float4*>(As + ((buf * BM + r) * LDK + kq * 4)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int r = (t >> 2) + 64 * j;
+            if (r < BN) *reinterpret_cast<float4*>(Bs + ((buf * BN + r) * LDK + kq * 4)) = rb[j];
+        }
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        float4 fa[MT][2], fb[NT][2];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const float* src = As + ((buf * BM + (wm * MT + a) * 32 + li) * LDK + lh * 8);
+            fa[a][0] = *reinterpret_cast<const float4*>(src);
+            fa[a][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const float* src = Bs + ((buf * BN + (wn * NT + b) * 32 + li) * LDK + lh * 8);
+            fb[b][0] = *reinterpret_cast<const float4*>(src);
+            fb[b][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const float4 av4 = fa[a][kk >> 2];
+                const float av = (kk & 3) == 0 ? av4.x : (kk & 3) == 1 ? av4.y : (kk & 3) == 2 ? av4.z : av4.w;
+#pragma unroll
+                for (int b = 0; b < NT; ++b) {
+                    const float4 bv4 = fb[b][kk >> 2];
+                    const float bv = (kk & 3) == 0 ? bv4.x : (kk & 3) == 1 ? bv4.y : (kk & 3) == 2 ? bv4.z : bv4.w;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: row table (output offset, batch index) in LDS, then masked coalesced stores --------
+    int64_t* row_off = reinterpret_cast<int64_t*>(smem);
+    int* row_b = reinterpret_cast<int*>(smem + 2 * BM);
+    if (t < BM) {
+        const int64_t m = m0 + t;
+        int64_t off = -1;
+        int b = 0;
+        if (m < M) {
+            const int ox = (int)(m % p.OW);
+            const int64_t q = m / p.OW;
+            const int oy = (int)(q % p.OH);
+            b = (int)(q / p.OH);
+            off = (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout;
+        }
+        row_off[t] = off;
+        row_b[t] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int n = n0 + (wn * NT + b) * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int64_t off = row_off[row];
+                if (off < 0) continue;
+                float v = acc[a][b][r] * p.gain;
+                if (out_scale) v *= out_scale[(int64_t)row_b[row] * p.Cout + n];
+                v += bv;
+                if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                if (resid) v = (v + resid[off + n]) * p.resid_gain;
+                if (p.accumulate) y[off + n] += v; else y[off + n] = v;
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// weight gradient:  gw[o][k] += gain * sum_pixels G(p,o) * X(p,k)
+//   GEMM view: M = Cout, N = TY*TX*Cin, reduction over the B*OH*OW pixels.  Both operands are contiguous
+//   along their NON-reduced axis (channels), so tiles are stored pixel-major in LDS ([16][BM], [16][BN]) and
+//   MFMA operands are read with conflict-free ds_read_b32.  The pixel axis is split over blockIdx.y
+//   (split-K); partial tiles are combined with f32 atomics into the caller-zeroed gw.
+// =====================================================================================================
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ out_scale, ideas_conv_params p,
+                                                            int tiles_n, int64_t pix_per_split) {
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    constexpr int LDM = BM + 4, LDN = BN + 4;
+    constexpr int G_PER = (BK * BM / 4 + 255) / 256;
+    constexpr int X_PER = (BK * BN / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDM + LDN)];
+    float* Gs = smem;                     // [2][BK][LDM]
+    float* Xs = smem + 2 * BK * LDM;      // [2][BK][LDN]
+
+    const int t = threadIdx.x;
+    const int Ktot = p.TY * p.TX * p.Cin;
+    const int64_t P = (int64_t)p.B * p.OH * p.OW;
+    const int tile_n = blockIdx.x % tiles_n;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int o0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int64_t pbeg = (int64_t)blockIdx.y * pix_per_split;
+    const int64_t pend = (pbeg + pix_per_split < P) ? pbeg + pix_per_split : P;
+    if (pbeg >= pend) return;
+
+    // fixed per-thread columns
+    int g_pr[G_PER], g_o[G_PER];
+    bool g_ok[G_PER];
+#pragma unroll
+    for (int j = 0; j < G_PER; ++j) {
+        const int idx = t + 256 * j;
+        g_pr[j] = idx / (BM / 4);
+        const int oq = idx % (BM / 4);
+        g_o[j] = o0 + oq * 4;
+        g_ok[j] = (idx < BK * BM / 4) && (g_o[j] < p.Cout);
+    }
+    int x_pr[X_PER], x_col[X_PER], x_ci[X_PER], x_ty[X_PER], x_tx[X_PER];
+    bool x_ok[X_PER];
+#pragma unroll
+    for (int j = 0; j < X_PER; ++j) {
+        const int idx = t + 256 * j;
+        x_pr[j] = idx / (BN / 4);
+        const int kq = idx % (BN / 4);
+        const int k = n0 + kq * 4;
+        x_col[j] = kq * 4;
+        x_ok[j] = (idx < BK * BN / 4) && (k < Ktot);
+        const int kk = x_ok[j] ? k : 0;
+        const int tap = kk / p.Cin;
+        x_ci[j] = kk - tap * p.Cin;
+        x_ty[j] = tap / p.TX;
+        x_tx[j] = tap - x_ty[j] * p.TX;
+    }
+
+    float4 rg[G_PER], rx[X_PER];
+    auto gload = [&](int64_t pstep) {
+#pragma unroll
+        for (int j = 0; j < G_PER; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t pp = pstep + g_pr[j];
+            if (g_ok[j] && pp < pend) {
+                const int ox = (int)(pp % p.OW);
+                const int64_t q = pp / p.OW;
+                const int oy = (int)(q % p.OH);
+                const int b = (int)(q / p.OH);
+                v = *reinterpret_cast<const float4*>(
+                    gy + (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + g_o[j]);
+                if (out_scale) v = mul4(v, *reinterpret_cast<const float4*>(out_scale + (int64_t)b * p.Cout + g_o[j]));
+            }
+            rg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < X_PER; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t pp = pstep + x_pr[j];
+            if (x_ok[j] && pp < pend) {
+                const int ox = (int)(pp % p.OW);
+                const int64_t q = pp / p.OW;
+                const int oy = (int)(q % p.OH);
+                const int b = (int)(q / p.OH);
+                int iy = oy * p.sy + x_ty[j] * p.dy + p.offy;
+                int ix = ox * p.sx + x_tx[j] * p.dx + p.offx;
+                bool ok = true;
+                if (p.reflect) {
+                    iy = reflect_coord(iy, p.IH);
+                    ix = reflect_coord(ix, p.IW);
+                } else {
+                    ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                }
+                if (ok) {
+                    v = *reinterpret_cast<const float4*>(x + (((int64_t)b * p.IH + iy) * p.IW + ix) * p.Cin + x_ci[j]);
+                    if (in_scale) v = mul4(v, *reinterpret_cast<const float4*>(in_scale + (int64_t)b * p.Cin + x_ci[j]));
+                }
+            }
+            rx[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < G_PER; ++j) {
+            const int idx = t + 256 * j;
+            if (idx < BK * BM / 4)
+                *reinterpret_cast<float4*>(Gs + ((buf * BK + g_pr[j]) * LDM + (idx % (BM / 4)) * 4)) = rg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < X_PER; ++j) {
+            const int idx = t + 256 * j;
+            if (idx < BK * BN / 4) *reinterpret_cast<float4*>(Xs + ((buf * BK + x_pr[j]) * LDN + x_col[j])) = rx[j];
+        }
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int64_t nsteps = (pend - pbeg + BK - 1) / BK;
+    gload(pbeg);
+    lstore(0);
+    __syncthreads();
+    for (int64_t s = 0; s < nsteps; ++s) {
+        const int buf = (int)(s & 1);
+        if (s + 1 < nsteps) gload(pbeg + (s + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) av[a] = Gs[(buf * BK + lh * 8 + kk) * LDM + (wm * MT + a) * 32 + li];
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bv[b] = Xs[(buf * BK + lh * 8 + kk) * LDN + (wn * NT + b) * 32 + li];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int k = n0 + (wn * NT + b) * 32 + li;
+        if (k >= Ktot) continue;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < p.Cout) atomicAdd(&gw[(int64_t)o * Ktot + k], acc[a][b][r] * p.gain);
+            }
+        }
+    }
+}
+
+int check_conv(const ideas_conv_params* p) {
+    if (!p) return IDEAS_E_NULL;
+    if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->YH <= 0 || p->YW <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;
+    if (p->OH <= 0 || p->OW <= 0 || p->TY <= 0 || p->TX <= 0 || p->osy <= 0 || p->osx <= 0) return IDEAS_E_SHAPE;
+    if ((p->OH - 1) * p->osy + p->ooy >= p->YH || (p->OW - 1) * p->osx + p->oox >= p->YW || p->ooy < 0 || p->oox < 0)
+        return IDEAS_E_SHAPE;
+    return IDEAS_OK;
+}
+
+}  // namespace
+
+extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
+                                const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
+                                void* stream_) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!y || !x || !wmat) return IDEAS_E_NULL;
+    int rc = check_conv(p);
+    if (rc) return rc;
+    if (p->Cin % 4) return IDEAS_E_ALIGN;
+    if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+#define LAUNCH_FWD(WM, WN, MT, NT)                                                                               \
+    do {                                                                                                         \
+        constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;                                                    \
+        const int64_t tm = ideas_cdiv(M, BM_);                                                                   \
+        const int tn = (int)ideas_cdiv(p->Cout, BN_);                                                            \
+        if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;                                                        \
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT>), dim3((unsigned)(tm * tn)), dim3(256), 0, stream, \
+                           (float*)y, (const float*)x, (const float*)wmat, in_scale, out_scale, bias,            \
+                           (const float*)resid, *p, tn);                                                         \
+    } while (0)
+    if (p->Cout > 64) LAUNCH_FWD(2, 2, 2, 2);        // 128 x 128
+    else if (p->Cout > 32) LAUNCH_FWD(2, 2, 2, 1);   // 128 x 64
+    else LAUNCH_FWD(4, 1, 1, 1);                     // 128 x 32
+#undef LAUNCH_FWD
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                                const ideas_conv_params* p, int dtype, void* stream_) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!gw || !gy || !x) return IDEAS_E_NULL;
+    int rc = check_conv(p);
+    if (rc) return rc;
+    if (p->Cin % 4 || p->Cout % 4) return IDEAS_E_ALIGN;
+    if (!ideas_aligned16(x) || !ideas_aligned16(gy) || (in_scale && !ideas_aligned16(in_scale)) ||
+        (out_scale && !ideas_aligned16(out_scale)))
+        return IDEAS_E_ALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t P = (int64_t)p->B * p->OH * p->OW;
+    const int Ktot = p->TY * p->TX * p->Cin;
+#define LAUNCH_WG(WM, WN, MT, NT)                                                                                 \
+    do {                                                                                                          \
+        constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;                                                     \
+        const int tm = (int)ideas_cdiv(p->Cout, BM_);                                                             \
+        const int tn = (int)ideas_cdiv(Ktot, BN_);                                                                \
+        const int64_t tiles = (int64_t)tm * tn;                                                                   \
+        int64_t splits = ideas_cdiv(1024, tiles);                                                                 \
+        const int64_t max_splits = ideas_cdiv(P, 8 * BK);                                                         \
+        if (splits > max_splits) splits = max_splits;                                                             \
+        if (splits < 1) splits = 1;                                                                               \
+        if (splits > 65535) splits = 65535;                                                                       \
+        int64_t per = ideas_cdiv(ideas_cdiv(P, splits), BK) * BK;                                                 \
+        splits = ideas_cdiv(P, per);                                                                              \
+        hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), \
+                           0, stream, gw, (const float*)gy, (const float*)x, in_scale, out_scale, *p, tn, per);   \
+    } while (0)
+    if (p->Cout > 64) LAUNCH_WG(2, 2, 2, 2);         // 128 (o) x 128 (k)
+    else if (p->Cout > 32) LAUNCH_WG(2, 2, 1, 2);    // 64 x 128
+    else LAUNCH_WG(1, 4, 1, 1);                      // 32 x 128
+#undef LAUNCH_WG
+    return ideas_launch_status();
+}

@@ -1,0 +1,94 @@
+// Small reductions around the modulated convolution (stylegan2/model.py:239-244).
+//
+//   ideas_demod      d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + eps): one wavefront per (b,o), 64-lane shuffle
+//                    reduction over Cin.  This is the reference's weight.pow(2).sum([2,3,4]) without the
+//                    [B,Cout,Cin,3,3] per-sample weight tensor: sum_{i,k}(scale*W[o,i,k]*s[b,i])^2
+//                    = sum_i s[b,i]^2 * (scale^2 * sum_k W[o,i,k]^2).
+//   ideas_pixel_dot  out[b,c] += sum_p a[b,p,c] * g[b,p,c] (NHWC): the two per-sample reductions the modconv
+//                    backward needs (d style = <x, dx/s>, d demod = <dy, y/d>).
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const float* __restrict__ s,
+                                                    const float* __restrict__ wsq, int B, int Cin, int Cout, float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
+    if (idx >= (int64_t)B * Cout) return;
+    const int b = (int)(idx / Cout), o = (int)(idx % Cout);
+    const float* sp = s + (int64_t)b * Cin;
+    const float* wp = wsq + (int64_t)o * Cin;
+    float acc = 0.f;
+    for (int i = lane; i < Cin; i += 64) { const float sv = sp[i]; acc = fmaf(sv * sv, wp[i], acc); }
+    acc = wave_sum(acc);
+    if (lane == 0) d[idx] = rsqrtf(acc + eps);
+}
+
+__global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                        const float* __restrict__ g, int64_t P, int C,
+                                                        int64_t pix_per_block) {
+    extern __shared__ float s_acc[];
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s_acc[c] = 0.f;
+    __syncthreads();
+    const float* ab = a + (int64_t)b * P * C;
+    const float* gb = g + (int64_t)b * P * C;
+    if ((C & 3) == 0) {
+        const int C4 = C >> 2;
+        auto dot_rows = [&](int c4, int pr, int R) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t pp = p0 + pr; pp < p1; pp += R) {
+                const float4 av = *reinterpret_cast<const float4*>(ab + pp * C + c4 * 4);
+                const float4 gv = *reinterpret_cast<const float4*>(gb + pp * C + c4 * 4);
+                acc.x = fmaf(av.x, gv.x, acc.x); acc.y = fmaf(av.y, gv.y, acc.y);
+                acc.z = fmaf(av.z, gv.z, acc.z); acc.w = fmaf(av.w, gv.w, acc.w);
+            }
+            atomicAdd(&s_acc[c4 * 4 + 0], acc.x); atomicAdd(&s_acc[c4 * 4 + 1], acc.y);
+            atomicAdd(&s_acc[c4 * 4 + 2], acc.z); atomicAdd(&s_acc[c4 * 4 + 3], acc.w);
+        };
+        if (C4 <= 256) {
+            // thread = (pixel row pr, channel quad c4): fixed channels per thread, coalesced along C
+            const int R = 256 / C4;
+            const int c4 = (int)threadIdx.x % C4, pr = (int)threadIdx.x / C4;
+            if (pr < R) dot_rows(c4, pr, R);
+        } else {
+            for (int c4 = threadIdx.x; c4 < C4; c4 += 256) dot_rows(c4, 0, 1);
+        }
+    } else {
+        for (int64_t i = p0 * C + threadIdx.x; i < p1 * C; i += blockDim.x)
+            atomicAdd(&s_acc[(int)(i % C)], ab[i] * gb[i]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(int64_t)b * C + c], s_acc[c]);
+}
+
+}  // namespace
+
+extern "C" int ideas_demod(float* d, const float* s, const float* wsq, int B, int Cin, int Cout, float eps,
+                           void* stream) {
+    if (!d || !s || !wsq) return IDEAS_E_NULL;
+    if (B <= 0 || Cin <= 0 || Cout <= 0) return IDEAS_E_SHAPE;
+    const int64_t waves = (int64_t)B * Cout;
+    hipLaunchKernelGGL(demod_kernel, dim3((unsigned)ideas_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, d, s, wsq,
+                       B, Cin, Cout, eps);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, int C, int dtype,
+                               void* stream) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!out || !a || !g) return IDEAS_E_NULL;
+    if (B <= 0 || P <= 0 || C <= 0 || C > 12288 || B > 65535) return IDEAS_E_SHAPE;
+    if ((C & 3) == 0 && (!ideas_aligned16(a) || !ideas_aligned16(g))) return IDEAS_E_ALIGN;
+    int64_t chunks = ideas_cdiv(2048, B);
+    const int64_t max_chunks = ideas_cdiv(P, 64);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    const int64_t per = ideas_cdiv(P, chunks);
+    chunks = ideas_cdiv(P, per);
+    hipLaunchKernelGGL(pixel_dot_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), (size_t)C * sizeof(float),
+                       (hipStream_t)stream, out, (const float*)a, (const float*)g, P, C, per);
+    return ideas_launch_status();
+}

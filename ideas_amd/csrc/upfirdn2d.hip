@@ -1,0 +1,216 @@
+// upfirdn2d for gfx950: zero-stuff / pad / FIR (flipped) / decimate.
+//
+// Replaces upfirdn2d_kernel + upfirdn2d_kernel_large (stylegan2/op/upfirdn2d_kernel.cu:49-207).  On the IDEAS
+// path this op is only ever a 4x4 blur with up = down = 1, pure HBM traffic: read the plane
+// once, write it once.  Three kernels:
+//   * blur4_nhwc  — the fast path.  Channels are innermost, so a thread owns 4 channels of one output
+//                   column and marches down the rows with a 4x4 register window: 4 x 16-byte loads and one
+//                   16-byte store per output, every access coalesced along C, no LDS needed.
+//   * blur_nchw_tile — NCHW (the reference's layout): LDS-staged (TH+kh-1) x (TW+kw-1) input tile per plane.
+//   * generic     — any up/down/kernel <= 8x8, either layout, one output per thread (the op's full contract).
+#include "common.hpp"
+
+namespace {
+
+struct FirParams {
+    int B, C, in_h, in_w, out_h, out_w, kh, kw;
+    int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+    float gain;
+    int flip;
+};
+
+// ---------------- generic: out[oy,ox] = sum_k U[oy*down + ky - pad0] * Kf[ky] ----------------------
+template <bool NHWC>
+__global__ __launch_bounds__(256) void upfirdn2d_generic(float* __restrict__ y, const float* __restrict__ x,
+                                                         const float* __restrict__ fir, FirParams p) {
+    __shared__ float sk[64];
+    for (int t = threadIdx.x; t < p.kh * p.kw; t += blockDim.x) {
+        int ky = t / p.kw, kx = t % p.kw;
+        int src = p.flip ? (p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx) : t;
+        sk[t] = fir[src] * p.gain;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)p.B * p.C * p.out_h * p.out_w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c, ox, oy, b;
+        int64_t r = i;
+        if (NHWC) {
+            c = (int)(r % p.C); r /= p.C;
+            ox = (int)(r % p.out_w); r /= p.out_w;
+            oy = (int)(r % p.out_h); b = (int)(r / p.out_h);
+        } else {
+            ox = (int)(r % p.out_w); r /= p.out_w;
+            oy = (int)(r % p.out_h); r /= p.out_h;
+            c = (int)(r % p.C); b = (int)(r / p.C);
+        }
+        float acc = 0.f;
+        for (int ky = 0; ky < p.kh; ++ky) {
+            int uy = oy * p.down_y + ky - p.pad_y0;
+            if (uy < 0 || uy % p.up_y) continue;
+            int iy = uy / p.up_y;
+            if (iy >= p.in_h) continue;
+            for (int kx = 0; kx < p.kw; ++kx) {
+                int ux = ox * p.down_x + kx - p.pad_x0;
+                if (ux < 0 || ux % p.up_x) continue;
+                int ix = ux / p.up_x;
+                if (ix >= p.in_w) continue;
+                int64_t src = NHWC ? (((int64_t)b * p.in_h + iy) * p.in_w + ix) * p.C + c
+                                   : (((int64_t)b * p.C + c) * p.in_h + iy) * p.in_w + ix;
+                acc += x[src] * sk[ky * p.kw + kx];
+            }
+        }
+        y[i] = acc;
+    }
+}
+
+// ---------------- NHWC 4x4 blur, up = down = 1 ---------------------------------------------------
+// thread = (b, row-segment, ox, c4); window w[r][t] holds input rows iy0..iy0+3 at columns ix0..ix0+3
+#define BLUR_ROWS 16
+__global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const float4* __restrict__ x,
+                                                  const float* __restrict__ fir, FirParams p) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) {
+        int t = threadIdx.x;
+        int src = p.flip ? 15 - t : t;
+        sk[t] = fir[src] * p.gain;
+    }
+    __syncthreads();
+    const int C4 = p.C >> 2;
+    const int segs = (p.out_h + BLUR_ROWS - 1) / BLUR_ROWS;
+    const int64_t total = (int64_t)p.B * segs * p.out_w * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int c4 = (int)(r % C4); r /= C4;
+    const int ox = (int)(r % p.out_w); r /= p.out_w;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int oy0 = seg * BLUR_ROWS;
+    const int oy1 = (oy0 + BLUR_ROWS < p.out_h) ? oy0 + BLUR_ROWS : p.out_h;
+    const int ix0 = ox - p.pad_x0;
+    float k[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) k[t] = sk[t];
+
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
+    bool colok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) colok[t] = (ix0 + t >= 0) && (ix0 + t < p.in_w);
+
+    float4 w[4][4];
+    auto load_row = [&](int iy, float4 (&dst)[4]) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const float4* xr = xb + ((int64_t)iy * p.in_w + ix0) * C4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t] = (rowok && colok[t]) ? xr[(int64_t)t * C4] : zero;
+    };
+    const int iy0 = oy0 - p.pad_y0;
+    load_row(iy0 + 0, w[0]);
+    load_row(iy0 + 1, w[1]);
+    load_row(iy0 + 2, w[2]);
+    float4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    for (int oy = oy0; oy < oy1; ++oy) {
+        load_row(oy - p.pad_y0 + 3, w[3]);
+        float4 acc = zero;
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float kk = k[ry * 4 + t];
+                acc.x += w[ry][t].x * kk; acc.y += w[ry][t].y * kk;
+                acc.z += w[ry][t].z * kk; acc.w += w[ry][t].w * kk;
+            }
+        yb[(int64_t)oy * p.out_w * C4] = acc;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { w[0][t] = w[1][t]; w[1][t] = w[2][t]; w[2][t] = w[3][t]; }
+    }
+}
+
+// ---------------- NCHW tiled blur, up = down = 1, k <= 4 -------------------------------------------
+#define TNH 16
+#define TNW 64
+__global__ __launch_bounds__(256) void blur_nchw_tile(float* __restrict__ y, const float* __restrict__ x,
+                                                      const float* __restrict__ fir, FirParams p) {
+    __shared__ float sk[16];
+    __shared__ float sx[TNH + 3][TNW + 3 + 1];
+    if (threadIdx.x < 16) {
+        int t = threadIdx.x;
+        int ky = t >> 2, kx = t & 3;
+        float v = 0.f;
+        if (ky < p.kh && kx < p.kw) {
+            int src = p.flip ? (p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx) : ky * p.kw + kx;
+            v = fir[src] * p.gain;
+        }
+        sk[t] = v;
+    }
+    const int tiles_x = (p.out_w + TNW - 1) / TNW;
+    const int tiles_y = (p.out_h + TNH - 1) / TNH;
+    int64_t bid = blockIdx.x;
+    const int tx = (int)(bid % tiles_x); bid /= tiles_x;
+    const int ty = (int)(bid % tiles_y);
+    const int64_t plane = bid / tiles_y;
+    const int oy0 = ty * TNH, ox0 = tx * TNW;
+    const float* xp = x + plane * p.in_h * p.in_w;
+    for (int t = threadIdx.x; t < (TNH + 3) * (TNW + 3); t += blockDim.x) {
+        int ry = t / (TNW + 3), rx = t % (TNW + 3);
+        int iy = oy0 + ry - p.pad_y0, ix = ox0 + rx - p.pad_x0;
+        float v = 0.f;
+        if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
+        sx[ry][rx] = v;
+    }
+    __syncthreads();
+    float* yp = y + plane * p.out_h * p.out_w;
+    for (int t = threadIdx.x; t < TNH * TNW; t += blockDim.x) {
+        int ry = t / TNW, rx = t % TNW;
+        int oy = oy0 + ry, ox = ox0 + rx;
+        if (oy >= p.out_h || ox >= p.out_w) continue;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) acc += sx[ry + ky][rx + kx] * sk[ky * 4 + kx];
+        yp[(int64_t)oy * p.out_w + ox] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h,
+                               int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                               int pad_y0, float gain, int flip, int layout, int dtype, void* stream_) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!y || !x || !fir) return IDEAS_E_NULL;
+    if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return IDEAS_E_SHAPE;
+    if (kh <= 0 || kw <= 0 || kh > 8 || kw > 8) return IDEAS_E_UNSUPPORTED;
+    if (up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0) return IDEAS_E_SHAPE;
+    if (layout != IDEAS_NCHW && layout != IDEAS_NHWC) return IDEAS_E_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    FirParams p{B, C, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, gain, flip};
+    const bool unit = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1;
+    if (unit && layout == IDEAS_NHWC && kh == 4 && kw == 4 && (C % 4 == 0) && ideas_aligned16(x) && ideas_aligned16(y)) {
+        const int segs = (out_h + BLUR_ROWS - 1) / BLUR_ROWS;
+        const int64_t total = (int64_t)B * segs * out_w * (C / 4);
+        const int64_t grid = ideas_cdiv(total, 256);
+        if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
+        hipLaunchKernelGGL(blur4_nhwc, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
+        return ideas_launch_status();
+    }
+    if (unit && layout == IDEAS_NCHW && kh <= 4 && kw <= 4) {
+        const int64_t grid = (int64_t)B * C * ideas_cdiv(out_h, TNH) * ideas_cdiv(out_w, TNW);
+        if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
+        hipLaunchKernelGGL(blur_nchw_tile, dim3((unsigned)grid), dim3(256), 0, stream, (float*)y, (const float*)x, fir, p);
+        return ideas_launch_status();
+    }
+    const int64_t total = (int64_t)B * C * out_h * out_w;
+    int64_t grid = ideas_cdiv(total, 256);
+    if (grid > 65536) grid = 65536;
+    if (layout == IDEAS_NHWC)
+        hipLaunchKernelGGL(upfirdn2d_generic<true>, dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
+                           (const float*)x, fir, p);
+    else
+        hipLaunchKernelGGL(upfirdn2d_generic<false>, dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
+                           (const float*)x, fir, p);
+    return ideas_launch_status();
+}

@@ -1,0 +1,145 @@
+"""Layer library of the IDEAS networks on the ideas_amd ops.
+
+Host-side mirror of the subset of stylegan2/model.py that models.py imports (models.py:7):
+``make_kernel`` (:22-30), ``Blur`` (:75-91), ``EqualConv2d`` (:94-123), ``EqualLinear`` (:132-161),
+``ScaledLeakyReLU`` (:169-178), ``ModulatedConv2d`` (:181-277), ``StyledConv_without_noise`` (:343-377).
+Same constructor signatures, parameter names, shapes and *creation order* (so ``torch.manual_seed(s)``
+reproduces the reference's initial weights and state-dicts interchange), but every forward runs on the
+gfx950 kernels: activations NHWC, conv weights kept OHWI in memory, the equalised-lr scale folded into the
+kernel epilogue, no per-sample weight tensors.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .op import FusedLeakyReLU, conv2d, fused_leaky_relu, modulated_conv2d, upfirdn2d
+
+CL = torch.channels_last
+
+
+def make_kernel(k: Sequence[float]) -> torch.Tensor:
+    """Normalised 2-D FIR from 1-D taps (outer product) or a 2-D table."""
+    t = torch.as_tensor(k, dtype=torch.float32)
+    if t.dim() == 1:
+        t = t.unsqueeze(0) * t.unsqueeze(1)
+    return t / t.sum()
+
+
+class Blur(nn.Module):
+    """4x4 FIR with explicit (pad0, pad1), optionally x upsample_factor^2 gain."""
+
+    def __init__(self, kernel, pad, upsample_factor: int = 1):
+        super().__init__()
+        fir = make_kernel(kernel)
+        if upsample_factor > 1:
+            fir = fir * (upsample_factor ** 2)
+        self.register_buffer("kernel", fir)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    """Conv with N(0,1) weights and run-time 1/sqrt(fan_in) scale (applied inside the kernel)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        w = torch.randn(out_channel, in_channel, kernel_size, kernel_size)
+        self.weight = nn.Parameter(w.contiguous(memory_format=CL))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input, reflect_pad: int = 0):
+        if reflect_pad:
+            return conv2d(input, self.weight, self.bias, stride=self.stride, padding=reflect_pad, reflect=True,
+                          gain=self.scale)
+        return conv2d(input, self.weight, self.bias, stride=self.stride, padding=self.padding, gain=self.scale)
+
+    def __repr__(self):
+        o, i, k, _ = self.weight.shape
+        return f"{self.__class__.__name__}({i}, {o}, {k}, stride={self.stride}, padding={self.padding})"
+
+
+class EqualLinear(nn.Module):
+    """Linear with equalised learning rate; optional fused bias + leaky-ReLU."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            return fused_leaky_relu(F.linear(input, self.weight * self.scale), self.bias * self.lr_mul)
+        b = None if self.bias is None else self.bias * self.lr_mul
+        return F.linear(input, self.weight * self.scale, bias=b)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
+
+
+class ScaledLeakyReLU(nn.Module):
+    """``leaky_relu(x) * sqrt(2)`` — the bias-free activation (not instantiated by any IDEAS net)."""
+
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return fused_leaky_relu(input, None, self.negative_slope, math.sqrt(2))
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        if downsample:
+            raise NotImplementedError("IDEAS never builds a downsampling ModulatedConv2d (models.py:143-152)")
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+
+    def forward(self, input, style):
+        s = self.modulation(style)
+        fir = self.blur.kernel if self.upsample else None
+        return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
+                                eps=self.eps)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
+                f"upsample={self.upsample}, downsample={self.downsample})")
+
+
+class StyledConv_without_noise(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=(1, 3, 3, 1),
+                 demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        return self.activate(self.conv(input, style))

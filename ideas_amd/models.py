@@ -1,0 +1,331 @@
+"""The seven IDEAS networks on the ideas_amd layer library.
+
+Host-side mirror of the reference's models.py (EqualConvTranspose2d :11-46, ConvLayer :49-134,
+StyledResBlock :137-178, ResBlock :181-227, DisentanglementEncoder :230-268, Generator :271-306,
+StructureGenerator :309-329, ImageLevelDiscriminator :332-376, CooccurenceDiscriminator :379-426,
+DistributionDiscriminator :429-441, TensorExtractor :444-465, init_model :468-513).
+
+What is kept identical: class names, constructor arguments, attribute names, the positional indices inside
+every ``nn.Sequential`` and the order in which parameters are created — so state-dict keys/shapes match the
+reference checkpoint format and ``torch.manual_seed(s)`` yields the reference's initial weights.
+What differs: forwards run on the gfx950 kernels (NHWC), ``ReflectionPad2d`` is folded into the conv's gather
+instead of materialising a padded tensor, and residual merges use one fused multiply-add.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .model import (CL, Blur, EqualConv2d, EqualLinear, ScaledLeakyReLU,
+                    StyledConv_without_noise as StyledConv)
+from .op import FusedLeakyReLU, conv_transpose2d
+
+_INV_SQRT2 = 1.0 / math.sqrt(2)
+
+
+class EqualConvTranspose2d(nn.Module):
+    """Stride-2 transposed conv with equalised-lr weights [Cin, Cout, k, k] (only k=1 is used, in skips)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        if padding != 0:
+            raise NotImplementedError("IDEAS only uses padding=0 transposed convs (models.py:80-88)")
+        w = torch.randn(in_channel, out_channel, kernel_size, kernel_size)
+        self.weight = nn.Parameter(w.contiguous(memory_format=CL))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv_transpose2d(input, self.weight, self.bias, stride=self.stride, gain=self.scale)
+
+    def __repr__(self):
+        i, o, k, _ = self.weight.shape
+        return f"{self.__class__.__name__}({i}, {o}, {k}, stride={self.stride}, padding={self.padding})"
+
+
+def _blur_pads(n_taps: int, kernel_size: int, up: bool):
+    factor = 2
+    if up:
+        p = (n_taps - factor) - (kernel_size - 1)
+        return (p + 1) // 2 + factor - 1, p // 2 + 1
+    p = (n_taps - factor) + (kernel_size - 1)
+    return (p + 1) // 2, p // 2
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur] -> (ConvT -> Blur | [ReflectionPad] -> Conv) -> [FusedLeakyReLU | Tanh | ScaledLeakyReLU]."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, upsample=False, downsample=False,
+                 blur_kernel=(1, 3, 3, 1), bias=True, activate=True, padding="zero", tanh=False):
+        mods = []
+        conv_bias = bias and not activate
+        conv_pad, stride = 0, 1
+        if downsample:
+            mods.append(Blur(blur_kernel, pad=_blur_pads(len(blur_kernel), kernel_size, up=False)))
+            stride = 2
+        if upsample:
+            mods.append(EqualConvTranspose2d(in_channel, out_channel, kernel_size, padding=0, stride=2, bias=conv_bias))
+            mods.append(Blur(blur_kernel, pad=_blur_pads(len(blur_kernel), kernel_size, up=True)))
+        else:
+            if not downsample:
+                half = (kernel_size - 1) // 2
+                if padding == "zero":
+                    conv_pad = half
+                elif padding == "reflect":
+                    if half > 0:
+                        mods.append(nn.ReflectionPad2d(half))
+                elif padding != "valid":
+                    raise ValueError('Padding should be "zero", "reflect", or "valid"')
+            mods.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=conv_pad, stride=stride,
+                                    bias=conv_bias))
+        if activate:
+            if tanh:
+                mods.append(nn.Tanh())
+            elif bias:
+                mods.append(FusedLeakyReLU(out_channel))
+            else:
+                mods.append(ScaledLeakyReLU(0.2))
+        super().__init__(*mods)
+        self.padding = conv_pad
+
+    def forward(self, input):
+        x = input
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.ReflectionPad2d) and i + 1 < len(mods) and isinstance(mods[i + 1], EqualConv2d):
+                x = mods[i + 1](x, reflect_pad=m.padding[0])   # mirror padding folded into the conv gather
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
+def _merge(out, skip):
+    """(out + skip) / sqrt(2) as one fused op."""
+    return torch.add(out, skip).mul_(_INV_SQRT2) if not (out.requires_grad or skip.requires_grad) \
+        else (out + skip) * _INV_SQRT2
+
+
+class StyledResBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, style_dim, upsample, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.conv1 = StyledConv(in_channel, out_channel, 3, style_dim, upsample=upsample, blur_kernel=blur_kernel)
+        self.conv2 = StyledConv(out_channel, out_channel, 3, style_dim)
+        if upsample or in_channel != out_channel:
+            self.skip = ConvLayer(in_channel, out_channel, 1, upsample=upsample, blur_kernel=blur_kernel, bias=False,
+                                  activate=False)
+        else:
+            self.skip = None
+
+    def forward(self, input, style, noise=None):
+        out = self.conv2(self.conv1(input, style), style)
+        skip = input if self.skip is None else self.skip(input)
+        return _merge(out, skip)
+
+
+class ResBlock(nn.Module):
+    """conv1 in->out, conv2 out->out (optionally blur + stride 2), 1x1 skip; differs from stock StyleGAN2."""
+
+    def __init__(self, in_channel, out_channel, downsample, padding="zero", blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, out_channel, 3, padding=padding)
+        self.conv2 = ConvLayer(out_channel, out_channel, 3, downsample=downsample, padding=padding,
+                               blur_kernel=blur_kernel)
+        if downsample or in_channel != out_channel:
+            self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, blur_kernel=blur_kernel,
+                                  bias=False, activate=False)
+        else:
+            self.skip = None
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        skip = input if self.skip is None else self.skip(input)
+        return _merge(out, skip)
+
+
+class DisentanglementEncoder(nn.Module):
+    """E: image -> (structure [B,8,R/16,R/16], texture [B,2048])."""
+
+    def __init__(self, channel, structure_channel=8, texture_channel=2048, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        stem = [ConvLayer(3, channel, 1)]
+        width = channel
+        for i in range(1, 5):
+            nxt = channel * (2 ** i)
+            stem.append(ResBlock(width, nxt, downsample=True, padding="reflect", blur_kernel=blur_kernel))
+            width = nxt
+        self.stem = nn.Sequential(*stem)
+        self.structure = nn.Sequential(
+            ConvLayer(width, width, 1, blur_kernel=blur_kernel),
+            ConvLayer(width, structure_channel, 1, blur_kernel=blur_kernel),
+        )
+        self.texture = nn.Sequential(
+            ConvLayer(width, width * 2, 3, downsample=True, padding="valid", blur_kernel=blur_kernel),
+            ConvLayer(width * 2, width * 4, 3, downsample=True, padding="valid", blur_kernel=blur_kernel),
+            nn.AdaptiveAvgPool2d(1),
+            ConvLayer(width * 4, texture_channel, 1, tanh=True, blur_kernel=blur_kernel),
+        )
+
+    def forward(self, input):
+        feat = self.stem(input)
+        return self.structure(feat), torch.flatten(self.texture(feat), 1)
+
+
+class Generator(nn.Module):
+    """G: (structure, texture) -> image; 8 StyledResBlocks, the last four upsample."""
+
+    WIDTHS = (4, 8, 12, 16, 16, 16, 8, 4)
+    UPSAMPLE = (False, False, False, False, True, True, True, True)
+
+    def __init__(self, channel, structure_channel=8, texture_channel=2048, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        width = structure_channel
+        for mult, up in zip(self.WIDTHS, self.UPSAMPLE):
+            self.layers.append(StyledResBlock(width, channel * mult, texture_channel, up, blur_kernel))
+            width = channel * mult
+        self.to_rgb = ConvLayer(width, 3, 1, activate=False)
+
+    def forward(self, structure, texture, noises=None):
+        out = structure
+        for layer in self.layers:
+            out = layer(out, texture, None)
+        return self.to_rgb(out)
+
+
+class StructureGenerator(nn.Module):
+    """Gstru: secret tensor Z [B,N,h,w] -> structure code."""
+
+    def __init__(self, channel, N=1, structure_channel=8, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        c = channel
+        self.structure = nn.Sequential(
+            ConvLayer(N, c, 1, blur_kernel=blur_kernel),
+            ResBlock(c, c * 2, downsample=False, padding="reflect", blur_kernel=blur_kernel),
+            ResBlock(c * 2, c * 4, downsample=False, padding="reflect", blur_kernel=blur_kernel),
+            ResBlock(c * 4, c * 2, downsample=False, padding="reflect", blur_kernel=blur_kernel),
+            ConvLayer(c * 2, structure_channel, 1, blur_kernel=blur_kernel),
+        )
+
+    def forward(self, noise):
+        return self.structure(noise)
+
+
+class ImageLevelDiscriminator(nn.Module):
+    """Dreal: image -> logit.  No minibatch-stddev layer (samples stay independent)."""
+
+    def __init__(self, size, channel_multiplier=1, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        cm = channel_multiplier
+        widths = {4: 512, 8: 512, 16: 512, 32: 512, 64: int(256 * cm), 128: int(128 * cm), 256: int(64 * cm),
+                  512: int(32 * cm), 1024: int(16 * cm)}
+        convs = [ConvLayer(3, widths[size], 1, blur_kernel=blur_kernel)]
+        width = widths[size]
+        for i in range(int(math.log(size, 2)), 2, -1):
+            nxt = widths[2 ** (i - 1)]
+            convs.append(ResBlock(width, nxt, downsample=True, blur_kernel=blur_kernel))
+            width = nxt
+        self.convs = nn.Sequential(*convs)
+        self.final_conv = ConvLayer(width, widths[4], 3, blur_kernel=blur_kernel)
+        self.final_linear = nn.Sequential(
+            EqualLinear(widths[4] * 4 * 4, widths[4], activation="fused_lrelu"),
+            EqualLinear(widths[4], 1),
+        )
+
+    def forward(self, input):
+        out = self.final_conv(self.convs(input))
+        return self.final_linear(out.reshape(out.shape[0], -1))
+
+
+class CooccurenceDiscriminator(nn.Module):
+    """Dco: patch vs. averaged reference-patch features -> logit."""
+
+    WIDTHS = (2, 4, 8, 12, 12, 24)
+    DOWN = (True, True, True, True, True, False)
+
+    def __init__(self, channel, size=256):
+        super().__init__()
+        encoder = [ConvLayer(3, channel, 1)]
+        width = channel
+        for mult, down in zip(self.WIDTHS, self.DOWN):
+            encoder.append(ResBlock(width, channel * mult, down))
+            width = channel * mult
+        k_size, feat_size = (3, 2 * 2) if size > 511 else (2, 1 * 1)
+        encoder.append(ConvLayer(width, channel * 12, k_size, padding="valid"))
+        self.encoder = nn.Sequential(*encoder)
+        self.linear = nn.Sequential(
+            EqualLinear(channel * 12 * 2 * feat_size, channel * 32, activation="fused_lrelu"),
+            EqualLinear(channel * 32, channel * 32, activation="fused_lrelu"),
+            EqualLinear(channel * 32, channel * 16, activation="fused_lrelu"),
+            EqualLinear(channel * 16, 1),
+        )
+
+    def forward(self, input, reference=None, ref_batch=None, ref_input=None):
+        out_input = self.encoder(input)
+        if ref_input is None:
+            ref = self.encoder(reference)
+            _, c, h, w = ref.shape
+            ref_input = ref.reshape(-1, ref_batch, c, h, w).mean(1)
+        out = torch.flatten(torch.cat((out_input, ref_input), 1), 1)
+        return self.linear(out), ref_input
+
+
+class DistributionDiscriminator(nn.Module):
+    """Ddist: texture code -> logit; four EqualLinear + lrelu (the last one too)."""
+
+    def __init__(self, texture_channel=2048):
+        super().__init__()
+        t = texture_channel
+        self.model = nn.Sequential(
+            EqualLinear(t, t // 4, activation="fused_lrelu"),
+            EqualLinear(t // 4, t // 16, activation="fused_lrelu"),
+            EqualLinear(t // 16, t // 64, activation="fused_lrelu"),
+            EqualLinear(t // 64, 1, activation="fused_lrelu"),
+        )
+
+    def forward(self, input):
+        return self.model(input)
+
+
+class TensorExtractor(nn.Module):
+    """Ex: recovered structure -> secret tensor estimate; its sign carries the bit decision."""
+
+    def __init__(self, channel, N=1, structure_channel=8, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        c = channel
+        self.extract = nn.Sequential(
+            ConvLayer(structure_channel, c * 2, 1, blur_kernel=blur_kernel),
+            ResBlock(c * 2, c * 4, downsample=False, padding="reflect", blur_kernel=blur_kernel),
+            ResBlock(c * 4, c * 2, downsample=False, padding="reflect", blur_kernel=blur_kernel),
+            ResBlock(c * 2, c, downsample=False, padding="reflect", blur_kernel=blur_kernel),
+            ConvLayer(c, N, 1, blur_kernel=blur_kernel),
+        )
+
+    def forward(self, input):
+        return self.extract(input)
+
+
+_FACTORY = {
+    "DisentanglementEncoder": lambda a: DisentanglementEncoder(a.channel, a.structure_channel, a.texture_channel, a.blur_kernel),
+    "Generator": lambda a: Generator(a.channel, a.structure_channel, a.texture_channel, a.blur_kernel),
+    "StructureGenerator": lambda a: StructureGenerator(a.channel, a.N, a.structure_channel, a.blur_kernel),
+    "ImageLevelDiscriminator": lambda a: ImageLevelDiscriminator(a.image_size, a.channel_multiplier, a.blur_kernel),
+    "CooccurenceDiscriminator": lambda a: CooccurenceDiscriminator(a.channel, a.image_size),
+    "DistributionDiscriminator": lambda a: DistributionDiscriminator(a.texture_channel),
+    "TensorExtractor": lambda a: TensorExtractor(a.channel, a.N, a.structure_channel, a.blur_kernel),
+}
+
+
+def init_model(model: str, args):
+    """Factory with the reference's names and ``args`` namespace (models.py:468-513)."""
+    try:
+        return _FACTORY[model](args)
+    except KeyError:
+        raise NotImplementedError(model) from None

@@ -1,0 +1,216 @@
+"""Convolutions with explicit first- and second-order backward on the gfx950 implicit-GEMM kernels.
+
+Plays the role the north_star calls ``conv2d_gradfix``: ``conv2d`` / ``conv_transpose2d`` whose backward is
+built from *differentiable* Functions (input-gradient, weight-gradient), so ``d_r1_loss``'s
+``autograd.grad(..., create_graph=True)`` (utils.py:112-118) works through the discriminators.  Replaces
+the ATen/cuDNN calls at stylegan2/model.py:115-121 (EqualConv2d) and models.py:32-38 (EqualConvTranspose2d).
+
+All activations are NHWC in memory (``torch.channels_last`` on a logical [B,C,H,W] tensor); weights
+[O,I,KH,KW] are used in OHWI order (free when the parameter itself is channels_last).  The equalised-lr
+``scale`` is folded into the kernel's accumulator gain instead of a ``weight * scale`` pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from .conv_plan import ConvGeom, Launch, convT_out_size, plan_dgrad, plan_fwd, plan_wgrad
+
+CL = torch.channels_last
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"ideas_amd conv: only float32 is implemented, got {t.dtype}")
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+def _params(L: Launch, gain: float, accumulate: bool = False, act: bool = False, alpha: float = 0.2,
+            act_gain: float = 1.0, resid_gain: float = 1.0) -> _lib.ConvParams:
+    return _lib.ConvParams(L.B, L.IH, L.IW, L.Cin, L.YH, L.YW, L.Cout, L.OH, L.OW, L.TY, L.TX, L.sy, L.sx, L.dy, L.dx,
+                           L.offy, L.offx, L.osy, L.osx, L.ooy, L.oox, L.reflect, int(act), alpha, act_gain,
+                           resid_gain, int(accumulate), gain)
+
+
+def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scale=None, out_scale=None, bias=None,
+               resid=None, act: bool = False, alpha: float = 0.2, act_gain: float = 1.0, resid_gain: float = 1.0,
+               accumulate: bool = False) -> None:
+    """Enqueue one forward-family launch (MFMA implicit GEMM when Cin % 4 == 0, VALU direct otherwise)."""
+    lib = _lib.load()
+    p = _params(L, gain, accumulate, act, alpha, act_gain, resid_gain)
+    w = L.wmat
+    if not w.is_contiguous():
+        w = w.contiguous()
+    fn = lib.ideas_conv_igemm if (L.Cin % 4 == 0) else lib.ideas_conv_direct
+    rc = fn(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(bias),
+            _lib.ptr(resid), C.byref(p), _lib.F32, _lib.stream_ptr())
+    _lib.check(rc, "ideas_conv_igemm" if L.Cin % 4 == 0 else "ideas_conv_direct")
+
+
+def launch_wgrad(gw: torch.Tensor, gy: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scale=None,
+                 out_scale=None) -> None:
+    lib = _lib.load()
+    p = _params(L, gain)
+    mfma = (L.Cin % 4 == 0) and (L.Cout % 4 == 0)
+    fn = lib.ideas_conv_wgrad if mfma else lib.ideas_conv_wgrad_direct
+    rc = fn(_lib.ptr(gw), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(out_scale), C.byref(p), _lib.F32,
+            _lib.stream_ptr())
+    _lib.check(rc, "ideas_conv_wgrad" if mfma else "ideas_conv_wgrad_direct")
+
+
+# ----------------------------------------------------------------------------------------------------
+# raw primitives of the "conv" geometry (no autograd).  lin = per-(b, input-channel) scale of the launch,
+# lout = per-(b, output-channel) scale of the launch.
+# ----------------------------------------------------------------------------------------------------
+
+def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None, act=False, act_gain=1.0,
+                 resid=None, resid_gain=1.0):
+    x = _nhwc(x)
+    L = plan_fwd(x.shape, w, g)
+    y = torch.empty((L.B, L.Cout, L.YH, L.YW), device=x.device, dtype=x.dtype, memory_format=CL)
+    if resid is not None:
+        resid = _nhwc(resid)
+    launch_fwd(y, x, L, gain, lin, lout, bias, resid, act=act, act_gain=act_gain, resid_gain=resid_gain)
+    return y
+
+
+def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=None, lout=None):
+    """Input gradient of the conv geometry (also: forward of the matching transposed conv)."""
+    gy = _nhwc(gy)
+    if g.reflect:
+        # gradient w.r.t. the reflect-padded input, then fold the mirrored border back
+        gp = ConvGeom(g.kh, g.kw, g.stride, 0, False)
+        ph, pw = in_hw[0] + 2 * g.pad, in_hw[1] + 2 * g.pad
+        gxp = conv_dgrad_raw(gy, w, gp, (ph, pw), gain, lin, lout)
+        like = gxp.new_empty((gxp.shape[0], gxp.shape[1], in_hw[0], in_hw[1]))
+        return torch.ops.aten.reflection_pad2d_backward(gxp.contiguous(), like, [g.pad] * 4)
+    launches, need_zero = plan_dgrad(gy.shape, w, g, in_hw)
+    b, ci = gy.shape[0], w.shape[1]
+    alloc = torch.zeros if need_zero else torch.empty
+    gx = alloc((b, ci, in_hw[0], in_hw[1]), device=gy.device, dtype=gy.dtype, memory_format=CL)
+    for L in launches:
+        launch_fwd(gx, gy, L, gain, lin, lout)
+    return gx
+
+
+def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None):
+    """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy."""
+    gy, x = _nhwc(gy), _nhwc(x)
+    L = plan_wgrad(x.shape, gy.shape, g)
+    gw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32, memory_format=CL)
+    launch_wgrad(gw, gy, x, L, gain, lin, lout)
+    return gw
+
+
+# ----------------------------------------------------------------------------------------------------
+# dense convolution with double backward
+# ----------------------------------------------------------------------------------------------------
+
+class _Conv(Function):
+    """y = gain * conv(x, w).  backward -> _ConvDgrad / _ConvWgrad (both differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, w, g: ConvGeom, gain: float):
+        ctx.g, ctx.gain = g, gain
+        x = _nhwc(x)
+        ctx.save_for_backward(x, w)
+        return conv_fwd_raw(x, w, g, gain)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(gy, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
+        if ctx.needs_input_grad[1]:
+            gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gain, tuple(w.shape))
+        return gx, gw, None, None
+
+
+class _ConvDgrad(Function):
+    """gx = gain * conv^T(gy, w).  Linear in (gy, w): its backward is the forward conv and a wgrad."""
+
+    @staticmethod
+    def forward(ctx, gy, w, g: ConvGeom, gain: float, in_hw):
+        ctx.g, ctx.gain, ctx.in_hw = g, gain, in_hw
+        gy = _nhwc(gy)
+        ctx.save_for_backward(gy, w)
+        return conv_dgrad_raw(gy, w, g, in_hw, gain)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = _Conv.apply(ggx, w, ctx.g, ctx.gain)
+        if ctx.needs_input_grad[1]:
+            g_w = _ConvWgrad.apply(gy, ggx, ctx.g, ctx.gain, tuple(w.shape))
+        return g_gy, g_w, None, None, None
+
+
+class _ConvWgrad(Function):
+    """gw = gain * sum gy (x) x.  Bilinear in (gy, x)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, g: ConvGeom, gain: float, w_shape):
+        ctx.g, ctx.gain = g, gain
+        gy, x = _nhwc(gy), _nhwc(x)
+        ctx.save_for_backward(gy, x)
+        return conv_wgrad_raw(gy, x, g, w_shape, gain)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        gy, x = ctx.saved_tensors
+        g_gy = g_x = None
+        if ctx.needs_input_grad[0]:
+            g_gy = _Conv.apply(x, ggw, ctx.g, ctx.gain)
+        if ctx.needs_input_grad[1]:
+            g_x = _ConvDgrad.apply(gy, ggw, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
+        return g_gy, g_x, None, None, None
+
+
+def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
+           padding: int = 0, reflect: bool = False, gain: float = 1.0) -> torch.Tensor:
+    """``gain * F.conv2d(input, weight, stride, padding) + bias`` (zero padding, or mirror padding if ``reflect``)."""
+    _lib.require_cuda(input, weight, bias)
+    g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
+    y = _Conv.apply(input, weight, g, float(gain))
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    return y
+
+
+class _ConvT(Function):
+    """Transposed conv (weight [I,O,KH,KW], stride s, padding 0) = dgrad of the conv reading w as [O'=I, I'=O]."""
+
+    @staticmethod
+    def forward(ctx, x, w, g: ConvGeom, gain: float):
+        ctx.g, ctx.gain = g, gain
+        x = _nhwc(x)
+        ctx.save_for_backward(x, w)
+        return conv_dgrad_raw(x, w, g, convT_out_size(x.shape[2], x.shape[3], g), gain)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _Conv.apply(gy, w, ctx.g, ctx.gain)
+        if ctx.needs_input_grad[1]:
+            gw = _ConvWgrad.apply(x, gy, ctx.g, ctx.gain, tuple(w.shape))
+        return gx, gw, None, None
+
+
+def conv_transpose2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
+                     gain: float = 1.0) -> torch.Tensor:
+    """``gain * F.conv_transpose2d(input, weight, stride=stride, padding=0) + bias``."""
+    _lib.require_cuda(input, weight, bias)
+    g = ConvGeom(weight.shape[2], weight.shape[3], stride, 0, False)
+    y = _ConvT.apply(input, weight, g, float(gain))
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    return y

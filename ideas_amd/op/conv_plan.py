@@ -1,0 +1,130 @@
+"""Geometry of the convolution family: turns conv / transposed-conv / their gradients into launches of the
+one parameterised kernel family (``ideas_conv_params``, include/ideas_hip.h).  Pure Python integers and
+tensor *views* only — no device work — so the derivations are unit-tested on CPU against F.conv2d.
+
+Conventions.  A "conv" geometry is (KH, KW, stride s, zero/reflect padding p) with weight w[O, I, KH, KW]:
+
+    forward   y[oy]  = sum_ky w[ky] * x[oy*s + ky - p]
+    dgrad     gx[iy] = sum_{ky : (iy + p - ky) % s == 0} w[ky] * gy[(iy + p - ky) / s]
+    wgrad     gw[ky] = sum_oy gy[oy] * x[oy*s + ky - p]
+
+A transposed conv (weight [I, O, KH, KW], stride s, padding 0) is the dgrad of the conv whose weight is the
+same tensor read as [O' = I, I' = O, KH, KW]; its own input gradient is that conv's forward and its weight
+gradient is that conv's wgrad with the roles of x and gy swapped.
+
+dgrad is decomposed by output parity r = iy mod s (one launch per (ry, rx)): with c = (r + p) mod s the
+contributing taps are ky = c + s*j, j = 0..J-1, J = ceil((KH - c) / s), and gy is read at q + e - j where
+iy = s*q + r and e = (r + p - c) / s — i.e. a stride-1 gather with tap step -1.  No multiply-by-zero work is
+issued for the stuffed zeros of a strided transposed conv (4 / 2 / 2 / 1 taps instead of 9 for 3x3, s = 2).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    kh: int
+    kw: int
+    stride: int = 1
+    pad: int = 0
+    reflect: bool = False
+
+    def out_size(self, ih: int, iw: int) -> Tuple[int, int]:
+        return ((ih + 2 * self.pad - self.kh) // self.stride + 1, (iw + 2 * self.pad - self.kw) // self.stride + 1)
+
+
+@dataclass
+class Launch:
+    """One kernel launch: integer fields of ideas_conv_params + the dense [Cout, TY*TX*Cin] weight matrix."""
+    B: int
+    IH: int
+    IW: int
+    Cin: int
+    YH: int
+    YW: int
+    Cout: int
+    OH: int
+    OW: int
+    TY: int
+    TX: int
+    sy: int
+    sx: int
+    dy: int
+    dx: int
+    offy: int
+    offx: int
+    osy: int = 1
+    osx: int = 1
+    ooy: int = 0
+    oox: int = 0
+    reflect: int = 0
+    wmat: Optional[torch.Tensor] = None      # forward family: [Cout, TY, TX, Cin] contiguous
+    w_slice: Optional[Tuple[int, int]] = None  # wgrad of a phase: (cy, cx) tap offsets inside the full kernel
+
+
+def w_ohwi(w: torch.Tensor) -> torch.Tensor:
+    """[O, I, KH, KW] parameter -> [O, KH, KW, I] contiguous (a view when the parameter is channels_last)."""
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def plan_fwd(x_shape, w: torch.Tensor, g: ConvGeom) -> Launch:
+    b, ci, ih, iw = x_shape
+    co = w.shape[0]
+    oh, ow = g.out_size(ih, iw)
+    return Launch(B=b, IH=ih, IW=iw, Cin=ci, YH=oh, YW=ow, Cout=co, OH=oh, OW=ow, TY=g.kh, TX=g.kw,
+                  sy=g.stride, sx=g.stride, dy=1, dx=1, offy=-g.pad, offx=-g.pad, reflect=int(g.reflect),
+                  wmat=w_ohwi(w))
+
+
+def _phase(r: int, p: int, s: int, k: int):
+    c = (r + p) % s
+    j = 0 if c >= k else -(-(k - c) // s)
+    e = (r + p - c) // s
+    return c, j, e
+
+
+def plan_dgrad(gy_shape, w: torch.Tensor, g: ConvGeom, in_hw: Tuple[int, int]) -> Tuple[List[Launch], bool]:
+    """Launches computing gx[B, I, IH, IW] from gy[B, O, OH, OW]; second value: must gx be pre-zeroed."""
+    if g.reflect:
+        raise ValueError("dgrad of a reflect-padded conv: compute the padded gradient (pad=0 geometry on the padded "
+                         "size) and fold it with reflection_pad2d_backward")
+    b, co, oh, ow = gy_shape
+    ci = w.shape[1]
+    ih, iw = in_hw
+    s, p = g.stride, g.pad
+    launches: List[Launch] = []
+    need_zero = False
+    for ry in range(s):
+        cy, jy, ey = _phase(ry, p, s, g.kh)
+        nqy = -(-(ih - ry) // s) if ih > ry else 0
+        for rx in range(s):
+            cx, jx, ex = _phase(rx, p, s, g.kw)
+            nqx = -(-(iw - rx) // s) if iw > rx else 0
+            if nqy <= 0 or nqx <= 0:
+                continue
+            if jy == 0 or jx == 0:
+                need_zero = True
+                continue
+            # wmat[i][(jy, jx, o)] = w[o][i][cy + s*jy][cx + s*jx]
+            wm = w[:, :, cy::s, cx::s].permute(1, 2, 3, 0).contiguous()
+            launches.append(Launch(B=b, IH=oh, IW=ow, Cin=co, YH=ih, YW=iw, Cout=ci, OH=nqy, OW=nqx, TY=jy, TX=jx,
+                                   sy=1, sx=1, dy=-1, dx=-1, offy=ey, offx=ex, osy=s, osx=s, ooy=ry, oox=rx,
+                                   wmat=wm))
+    return launches, need_zero
+
+
+def plan_wgrad(x_shape, gy_shape, g: ConvGeom) -> Launch:
+    """gw[O, KH, KW, I] (OHWI) from x[B, I, IH, IW] and gy[B, O, OH, OW]."""
+    b, ci, ih, iw = x_shape
+    _, co, oh, ow = gy_shape
+    return Launch(B=b, IH=ih, IW=iw, Cin=ci, YH=oh, YW=ow, Cout=co, OH=oh, OW=ow, TY=g.kh, TX=g.kw,
+                  sy=g.stride, sx=g.stride, dy=1, dx=1, offy=-g.pad, offx=-g.pad, reflect=int(g.reflect))
+
+
+def convT_out_size(ih: int, iw: int, g: ConvGeom) -> Tuple[int, int]:
+    """Output size of conv_transpose2d(stride s, padding p): (ih-1)*s - 2p + kh."""
+    return (ih - 1) * g.stride - 2 * g.pad + g.kh, (iw - 1) * g.stride - 2 * g.pad + g.kw

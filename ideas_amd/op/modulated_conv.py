@@ -1,0 +1,129 @@
+"""Modulated / demodulated 3x3 convolution without per-sample weights.
+
+Mirror of ``ModulatedConv2d.forward`` (stylegan2/model.py:236-277; same-resolution and upsample branches —
+the only two IDEAS instantiates, models.py:143-152).  The reference materialises a [B*Cout, Cin, 3, 3] weight
+per call and runs a ``groups=batch`` conv (B small convs for cuDNN).  Here the arithmetic is re-associated:
+
+    y[b,o] = (scale * d[b,o]) * sum_{i,k} W[o,i,k] * (s[b,i] * x[b,i, . + k])
+
+so ONE implicit GEMM with the shared weight serves the whole batch: ``s`` scales the activation tile while it
+is staged into LDS, ``d`` scales the accumulator in the epilogue (kernel: csrc/conv_igemm.hip).  The
+demodulation factor d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8), wsq = scale^2 * sum_k W^2, is a
+wavefront-shuffle reduction (csrc/modconv_aux.hip) instead of a pass over the per-sample weights.
+Difference to the reference's association is f32-roundoff class (SURVEY.md §7 measured 1.8e-6 abs on |y|~4).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, _nhwc
+from .conv_plan import ConvGeom, convT_out_size
+from .upfirdn2d import upfirdn2d
+
+
+def pixel_dot(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """out[b,c] = sum over pixels of a[b,c,h,w]*g[b,c,h,w] (both NHWC in memory)."""
+    a, g = _nhwc(a), _nhwc(g)
+    b, c, h, w = a.shape
+    out = torch.zeros((b, c), device=a.device, dtype=torch.float32)
+    rc = _lib.load().ideas_pixel_dot(_lib.ptr(out), _lib.ptr(a), _lib.ptr(g), b, h * w, c, _lib.F32, _lib.stream_ptr())
+    _lib.check(rc, "ideas_pixel_dot")
+    return out
+
+
+class _Demod(Function):
+    """d = rsqrt((s*s) @ wsq^T + eps) on the shuffle-reduction kernel; backward is three tiny matmuls."""
+
+    @staticmethod
+    def forward(ctx, s, wsq, eps):
+        s, wsq = s.contiguous(), wsq.contiguous()
+        b, cin = s.shape
+        cout = wsq.shape[0]
+        d = torch.empty((b, cout), device=s.device, dtype=torch.float32)
+        rc = _lib.load().ideas_demod(_lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq), b, cin, cout, float(eps), _lib.stream_ptr())
+        _lib.check(rc, "ideas_demod")
+        ctx.save_for_backward(s, wsq, d)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        s, wsq, d = ctx.saved_tensors
+        gq = -0.5 * gd * d * d * d                    # dq of (q + eps)^(-1/2)
+        gs = 2.0 * s * (gq @ wsq) if ctx.needs_input_grad[0] else None
+        gwsq = gq.t() @ (s * s) if ctx.needs_input_grad[1] else None
+        return gs, gwsq, None
+
+
+class _ModConv(Function):
+    """y = gain * d[b,o] * conv(s[b,i] * x, W)   (same-res, pad 1)  or the stride-2 transposed variant."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, up: bool, gain: float):
+        x = _nhwc(x)
+        s = s.contiguous()
+        d = None if d is None else d.contiguous()
+        k = w.shape[2]
+        if up:
+            g = ConvGeom(k, k, 2, 0, False)
+            wt = w.transpose(0, 1)  # read as conv weight [O'=Cin, I'=Cout]
+            y = conv_dgrad_raw(x, wt, g, convT_out_size(x.shape[2], x.shape[3], g), gain, lin=s, lout=d)
+        else:
+            g = ConvGeom(k, k, 1, k // 2, False)
+            y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d)
+        ctx.g, ctx.up, ctx.gain, ctx.has_d = g, up, gain, d is not None
+        ctx.save_for_backward(x, w, s, d if d is not None else s.new_zeros(0), y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, d, y = ctx.saved_tensors
+        d = d if ctx.has_d else None
+        g, gain = ctx.g, ctx.gain
+        gy = _nhwc(gy)
+        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
+        gx = gw = gs = gd = None
+        if need_x or need_s:
+            if ctx.up:
+                gx = conv_fwd_raw(gy, w.transpose(0, 1), g, gain, lin=d, lout=s)
+            else:
+                gx = conv_dgrad_raw(gy, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
+        if need_w:
+            if ctx.up:
+                wt_shape = (w.shape[1], w.shape[0], w.shape[2], w.shape[3])
+                gw = conv_wgrad_raw(x, gy, g, wt_shape, gain, lin=d, lout=s).transpose(0, 1)
+            else:
+                gw = conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, lin=s, lout=d)
+        if need_s:
+            # gx = s * (dL/d(s*x)); <x, gx> / s = <x, dL/d(s*x)>
+            dot = pixel_dot(x, gx)
+            gs = torch.where(s != 0, dot / s, torch.zeros_like(dot))
+        if need_d and d is not None:
+            gd = pixel_dot(gy, y) / d
+        return (gx if need_x else None), gw, gs, gd, None, None
+
+
+def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, demodulate: bool = True,
+                     upsample: bool = False, fir: Optional[torch.Tensor] = None, eps: float = 1e-8) -> torch.Tensor:
+    """``x`` [B,Cin,H,W]; ``weight`` [1,Cout,Cin,k,k] (the reference's parameter); ``style`` [B,Cin] = the
+    already-affine-transformed modulation (stylegan2/model.py:239).  ``fir`` = the 4x4 blur (x4 gain applied
+    here) used after the stride-2 transposed conv (stylegan2/model.py:202-208, 258-261)."""
+    _lib.require_cuda(x, weight, style)
+    w = weight[0] if weight.dim() == 5 else weight
+    cout, cin, k, _ = w.shape
+    scale = 1.0 / math.sqrt(cin * k * k)
+    d = None
+    if demodulate:
+        wsq = (w * w).sum(dim=(2, 3)) * (scale * scale)
+        d = _Demod.apply(style, wsq, eps)
+    y = _ModConv.apply(x, w, style, d, upsample, scale)
+    if upsample:
+        if fir is None:
+            raise RuntimeError("modulated_conv2d(upsample=True) needs the blur FIR")
+        p = (fir.shape[0] - 2) - (k - 1)
+        y = upfirdn2d(y, fir, pad=((p + 1) // 2 + 1, p // 2 + 1))
+    return y

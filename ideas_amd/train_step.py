@@ -1,0 +1,265 @@
+"""One IDEAS training iteration (D phase, lazy R1, G phase, Ex phase, EMA) on the ideas_amd networks.
+
+Host-side mirror of the hot loop of the reference's ``train()`` (train.py:48-221) and of the model /
+optimiser construction in its ``__main__`` (train.py:390-432).  The numbers it produces are the reference's;
+what differs is mechanical and documented in DESIGN.md:
+
+* every random draw of the iteration (Z, T2, crop boxes) is an explicit ``StepDraws`` input —
+  ``draw_step`` reproduces the reference's call order on the same three RNG streams;
+* during the D phase the generator side runs under ``no_grad`` (its parameters are frozen there, so the
+  reference builds no graph either);
+* the reference's second ``Loss_Ex.backward()`` re-traverses Ex -> E -> G -> Gstru only to obtain Ex's
+  gradient (train.py:214-215); here that gradient is taken over the Ex sub-graph alone
+  (``elide_second_backward=True``, bit-identical Ex gradient, ~9 % fewer step FLOPs) — set it False for the
+  literal traversal;
+* R1 uses a detached copy of X instead of flipping ``X.requires_grad`` in place;
+* gradients can be averaged across ranks (``reducer``) between backward and optimiser step — the
+  data-parallel path the reference only has in its vendored, unused trainer (stylegan2/train.py:426-438).
+"""
+from __future__ import annotations
+
+import argparse
+import random
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+from torch import optim
+from torch.nn import functional as F
+
+from .utils import (Box, accumulate, d_logistic_loss, d_r1_loss, draw_boxes, g_nonsaturating_loss,
+                    message_to_tensor, patchify_image, requires_grad, tensor_to_message)
+
+NET_CLASSES = {
+    "E": "DisentanglementEncoder", "G": "Generator", "Gstru": "StructureGenerator", "Ex": "TensorExtractor",
+    "Dreal": "ImageLevelDiscriminator", "Dco": "CooccurenceDiscriminator", "Ddist": "DistributionDiscriminator",
+}
+EMA_NETS = ("E", "G", "Gstru", "Ex")
+G_SIDE = ("E", "G", "Gstru")
+D_SIDE = ("Dreal", "Dco", "Ddist")
+
+
+def default_args(**over) -> argparse.Namespace:
+    """train.py:331-370 defaults (only the flags that reach the step)."""
+    a = argparse.Namespace(N=1, lambda_Ex=10.0, lr=0.002, batch_size=1, image_size=256, real_r1=10.0, texture_r1=1.0,
+                           dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=16, channel=32, channel_multiplier=1,
+                           structure_channel=8, texture_channel=2048, num_iters=100000, start_iter=0,
+                           blur_kernel=(1, 3, 3, 1), use_dco=True, elide_second_backward=True)
+    a.__dict__.update(over)
+    return a
+
+
+def build_trainer(args, device, init_model: Callable, with_ema: bool = True, dco_factory: Optional[Callable] = None):
+    """Eleven networks + three Adams exactly as train.py:390-432 (betas as floats: torch>=2 rejects the int 0)."""
+    t: Dict[str, object] = {}
+    for name in ("E", "G", "Gstru", "Ex", "Dreal", "Dco", "Ddist"):
+        if name == "Dco" and dco_factory is not None:
+            t[name] = dco_factory().to(device)
+        else:
+            t[name] = init_model(NET_CLASSES[name], args).to(device)
+    if with_ema:
+        for name in EMA_NETS:
+            t[name + "_ema"] = init_model(NET_CLASSES[name], args).to(device).eval()
+            accumulate(t[name + "_ema"], t[name], 0)
+    g_params = [p for n in G_SIDE for p in t[n].parameters()]
+    t["g_optim"] = optim.Adam(g_params, lr=args.lr, betas=(0.0, 0.99))
+    t["ex_optim"] = optim.Adam(t["Ex"].parameters(), lr=args.lr, betas=(0.0, 0.99))
+    r = args.d_reg_every / (args.d_reg_every + 1)
+    d_params = [p for n in D_SIDE for p in t[n].parameters()]
+    t["d_optim"] = optim.Adam(d_params, lr=args.lr * r, betas=(0.0 ** r, 0.99 ** r))
+    return t
+
+
+@dataclass
+class StepDraws:
+    """Every random draw of one iteration, in program order.  Z/T2 are already mapped to U(-1, 1)."""
+    Z_d: torch.Tensor = None
+    T2_d: torch.Tensor = None
+    boxes_d_fake: List[Box] = field(default_factory=list)
+    boxes_d_real: List[Box] = field(default_factory=list)
+    boxes_d_ref: List[Box] = field(default_factory=list)
+    Z_g: torch.Tensor = None
+    T2_g: torch.Tensor = None
+    boxes_g_fake: List[Box] = field(default_factory=list)
+    boxes_g_ref: List[Box] = field(default_factory=list)
+
+
+def draw_step(args, batch: int, image_size: int, device, generator: Optional[torch.Generator] = None) -> StepDraws:
+    """Draws in the reference's order: Z on the torch CPU stream (train.py:60), T2 on the device stream (:64),
+    boxes via torch CPU + Python ``random`` (utils.py:128-138); then the same for the G phase (:147-175)."""
+    s = image_size // 16
+    d = StepDraws()
+    d.Z_d = (torch.rand(size=(batch, args.N, s, s), dtype=torch.float) * 2 - 1).to(device)
+    d.T2_d = torch.rand((batch, args.texture_channel), device=device, generator=generator) * 2 - 1
+    if args.use_dco:
+        d.boxes_d_fake = draw_boxes(image_size, image_size, args.n_crop)
+        d.boxes_d_real = draw_boxes(image_size, image_size, args.n_crop)
+        d.boxes_d_ref = draw_boxes(image_size, image_size, args.ref_crop * args.n_crop)
+    d.Z_g = (torch.rand(size=(batch, args.N, s, s), dtype=torch.float) * 2 - 1).to(device)
+    d.T2_g = torch.rand((batch, args.texture_channel), device=device, generator=generator) * 2 - 1
+    if args.use_dco:
+        d.boxes_g_fake = draw_boxes(image_size, image_size, args.n_crop)
+        d.boxes_g_ref = draw_boxes(image_size, image_size, args.ref_crop * args.n_crop)
+    return d
+
+
+def _set_grads(params: Sequence[torch.Tensor], grads: Sequence[Optional[torch.Tensor]]) -> None:
+    """Install freshly computed gradients (a reducer folds them into its flat bucket afterwards)."""
+    for p, g in zip(params, grads):
+        p.grad = g
+
+
+def _params_of(trainer, names) -> List[torch.Tensor]:
+    return [p for n in names for p in trainer[n].parameters()]
+
+
+def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optional[StepDraws] = None,
+                    reducer=None, hook: Optional[Callable] = None) -> Dict[str, torch.Tensor]:
+    """Run one iteration in place on ``trainer``; returns the loss tensors (no host sync).
+
+    ``reducer(group_name, params)`` is called after each backward (``'d'``, ``'r1'``, ``'g'``, ``'ex'``) to
+    average gradients across ranks.  ``hook(tag, params)`` is a test hook called at the same points, just
+    before the optimiser step."""
+    T = trainer
+    if draws is None:
+        draws = draw_step(args, X.shape[0], X.shape[-1], X.device)
+    losses: Dict[str, torch.Tensor] = {}
+    d_params = _params_of(T, D_SIDE)
+    g_params = _params_of(T, G_SIDE)
+    ex_params = list(T["Ex"].parameters())
+
+    def _sync(tag, params):
+        if reducer is not None:
+            reducer(tag, params)
+        if hook is not None:
+            hook(tag, params)
+
+    # ------------------------------------------------------------------ D phase (train.py:48-102)
+    for n in ("E", "G", "Gstru", "Ex"):
+        requires_grad(T[n], False)
+    for n in D_SIDE:
+        requires_grad(T[n], True)
+    with torch.no_grad():
+        S1, T1 = T["E"](X)
+        S2 = T["Gstru"](draws.Z_d)
+        T2 = draws.T2_d
+        hat_X1 = T["G"](S1, T1)
+        hat_X2 = T["G"](S2, T1)
+        hat_X3 = T["G"](S2, T2)
+    fake_pred = T["Dreal"](torch.cat((hat_X1, hat_X2, hat_X3), 0))
+    real_pred = T["Dreal"](X)
+    losses["D_real_loss"] = d_logistic_loss(real_pred, fake_pred)
+    d_total = losses["D_real_loss"]
+    real_patch = ref_patch = None
+    if args.use_dco:
+        fake_patch = patchify_image(hat_X2, args.n_crop, boxes=draws.boxes_d_fake)
+        real_patch = patchify_image(X, args.n_crop, boxes=draws.boxes_d_real)
+        ref_patch = patchify_image(X, args.ref_crop * args.n_crop, boxes=draws.boxes_d_ref)
+        fake_tex, ref_input = T["Dco"](fake_patch, ref_patch, ref_batch=args.ref_crop)
+        real_tex, _ = T["Dco"](real_patch, ref_input=ref_input)
+        losses["D_texture_loss"] = d_logistic_loss(real_tex, fake_tex)
+        d_total = d_total + losses["D_texture_loss"]
+    losses["D_dist_loss"] = d_logistic_loss(T["Ddist"](T2), T["Ddist"](T1))
+    d_total = d_total + losses["D_dist_loss"]
+    T["d_optim"].zero_grad(set_to_none=False)
+    d_total.backward()
+    _sync("d", d_params)
+    T["d_optim"].step()
+    del fake_pred, real_pred, d_total, hat_X1, hat_X2, hat_X3
+
+    # ------------------------------------------------------------------ lazy R1 (train.py:105-129)
+    if iter_idx % args.d_reg_every == 0:
+        Xr = X.detach().clone().requires_grad_(True)
+        losses["D_real_r1_loss"] = d_r1_loss(T["Dreal"](Xr), Xr)
+        r1 = args.real_r1 / 3 * losses["D_real_r1_loss"] * args.d_reg_every
+        if args.use_dco:
+            rp = real_patch.detach().requires_grad_(True)
+            pred, _ = T["Dco"](rp, ref_patch, ref_batch=args.ref_crop)
+            losses["D_texture_r1_loss"] = d_r1_loss(pred, rp)
+            r1 = r1 + args.texture_r1 / 3 * losses["D_texture_r1_loss"] * args.d_reg_every
+        T2r = T2.detach().requires_grad_(True)
+        losses["D_dist_r1_loss"] = d_r1_loss(T["Ddist"](T2r), T2r)
+        r1 = r1 + args.dist_r1 / 3 * losses["D_dist_r1_loss"] * args.d_reg_every
+        T["d_optim"].zero_grad(set_to_none=False)
+        r1.backward()
+        _sync("r1", d_params)
+        T["d_optim"].step()
+        del r1, Xr
+
+    # ------------------------------------------------------------------ G phase (train.py:135-216)
+    for n in ("E", "G", "Gstru", "Ex"):
+        requires_grad(T[n], True)
+    for n in D_SIDE:
+        requires_grad(T[n], False)
+    S1, T1 = T["E"](X)
+    Z = draws.Z_g
+    S2 = T["Gstru"](Z)
+    T2 = draws.T2_g
+    hat_X1 = T["G"](S1, T1)
+    hat_X2 = T["G"](S2, T1)
+    hat_X3 = T["G"](S2, T2)
+    losses["G_rec_loss"] = F.l1_loss(hat_X1, X)
+    losses["G_real_loss"] = g_nonsaturating_loss(T["Dreal"](torch.cat((hat_X1, hat_X2, hat_X3), 0)))
+    losses["E_dist_loss"] = g_nonsaturating_loss(T["Ddist"](T1))
+    if args.use_dco:
+        fake_patch = patchify_image(hat_X2, args.n_crop, boxes=draws.boxes_g_fake)
+        ref_patch = patchify_image(X, args.ref_crop * args.n_crop, boxes=draws.boxes_g_ref)
+        pred, _ = T["Dco"](fake_patch, ref_patch, ref_batch=args.ref_crop)
+        losses["G_texture_loss"] = g_nonsaturating_loss(pred)
+    else:
+        losses["G_texture_loss"] = X.new_zeros(())
+    container = hat_X3 if iter_idx > args.num_iters * 0.8 else hat_X2
+    hat_S2, _ = T["E"](container)
+    losses["E_stru_loss"] = F.l1_loss(hat_S2, S2)
+    hat_Z = T["Ex"](hat_S2)
+    losses["Ex_loss"] = F.l1_loss(hat_Z, Z)
+    loss_g = losses["G_rec_loss"] + losses["G_texture_loss"] + 2 * losses["G_real_loss"]
+    loss_e = losses["E_dist_loss"] + losses["E_stru_loss"]
+    loss_total = loss_g + loss_e + args.lambda_Ex * losses["Ex_loss"]
+    losses["Loss_total"] = loss_total.detach()
+    losses["hat_Z"] = hat_Z.detach()
+
+    if args.elide_second_backward:
+        ex_grads = torch.autograd.grad(losses["Ex_loss"], ex_params, retain_graph=True)
+        g_grads = torch.autograd.grad(loss_total, g_params, allow_unused=True)
+        _set_grads(g_params, g_grads)
+        _sync("g", g_params)
+        T["g_optim"].step()
+        _set_grads(ex_params, ex_grads)
+        _sync("ex", ex_params)
+        T["ex_optim"].step()
+    else:
+        T["g_optim"].zero_grad(set_to_none=False)
+        loss_total.backward(retain_graph=True)
+        _sync("g", g_params)
+        T["g_optim"].step()
+        T["ex_optim"].zero_grad(set_to_none=False)
+        losses["Ex_loss"].backward()
+        _sync("ex", ex_params)
+        T["ex_optim"].step()
+
+    # ------------------------------------------------------------------ EMA (train.py:218-221)
+    accum = 0.5 ** (32 / (10 * 1000))
+    for n in EMA_NETS:
+        if n + "_ema" in T:
+            accumulate(T[n + "_ema"], T[n], accum)
+    return losses
+
+
+@torch.no_grad()
+def extraction_test(trainer, args, X: torch.Tensor, M: torch.Tensor, T2: torch.Tensor, use_x3: bool,
+                    jitter: Optional[torch.Tensor] = None, ema: bool = True):
+    """The sender/receiver block of train.py:249-286: bits -> Z -> S2 -> image -> S2' -> Z' -> bits."""
+    sfx = "_ema" if ema else ""
+    E, G, Gs, Ex = (trainer[n + sfx] for n in ("E", "G", "Gstru", "Ex"))
+    S1, T1 = E(X)
+    Z = message_to_tensor(M, sigma=1, delta=0.5, jitter=jitter).to(X.device)
+    Z = Z.reshape(S1.shape[0], args.N, S1.shape[2], S1.shape[3])
+    S2 = Gs(Z)
+    container = G(S2, T2 if use_x3 else T1)
+    hat_S2, _ = E(container)
+    hat_Z = Ex(hat_S2)
+    l1 = torch.mean(torch.abs(hat_Z - Z))
+    hat_M = tensor_to_message(hat_Z.reshape(Z.shape[0], -1), sigma=1)
+    acc = 1 - torch.mean(torch.abs(M.to(hat_M.device) - hat_M))
+    return hat_Z, hat_M, acc, l1

@@ -1,0 +1,148 @@
+/*
+ * ideas_hip.h — C ABI of libideas_hip.so, the MI355X (gfx950) kernels behind the IDEAS hot path.
+ *
+ * Drop-in boundary.  The reference binds two pybind11 modules whose single entry
+ * points take/return torch::Tensor:
+ *     fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)      stylegan2/op/fused_bias_act.cpp:11-21
+ *     upfirdn2d_op.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y,
+ *                            pad_x0, pad_x1, pad_y0, pad_y1)                   stylegan2/op/upfirdn2d.cpp:12-23
+ * and leaves every convolution to cuDNN through ATen (stylegan2/model.py:115-121,258,273; models.py:32-38).
+ * This library replaces all of them with plain-C entry points:
+ *
+ *   - raw device pointers, int dims, a dtype/layout enum and a hipStream_t (passed as void*);
+ *   - the CALLER allocates every output (so memory stays with its own allocator);
+ *   - no global state, no allocation, no host synchronisation: every call only enqueues on `stream`;
+ *   - return value: 0 = enqueued; negative = argument error (IDEAS_E_*); positive = hipError_t of the launch.
+ *
+ * Layouts.  IDEAS_NCHW is the reference's layout (bias index (i / inner) % C,
+ * fused_bias_act_kernel.cu:29).  IDEAS_NHWC is the MI355X fast path: channels innermost, so bias index is
+ * i % C, every load is a coalesced 16-byte vector and the 3x3 contraction's K axis (ky,kx,ci) is contiguous.
+ * The convolution entry points are NHWC-only.
+ */
+#ifndef IDEAS_HIP_H
+#define IDEAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDEAS_ABI_VERSION 1
+
+enum { IDEAS_NCHW = 0, IDEAS_NHWC = 1 };
+enum { IDEAS_F32 = 0 };
+
+enum {
+    IDEAS_OK = 0,
+    IDEAS_E_NULL = -1,      /* a required pointer is NULL                 */
+    IDEAS_E_SHAPE = -2,     /* a dimension is <= 0 or inconsistent        */
+    IDEAS_E_UNSUPPORTED = -3, /* dtype / layout / mode not implemented   */
+    IDEAS_E_ALIGN = -4      /* pointer or channel count not 16-B aligned where the kernel needs it */
+};
+
+int ideas_abi_version(void);
+const char* ideas_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * fused bias + leaky-ReLU.  Replaces fused_bias_act_op (fused_bias_act_kernel.cu:52-98).
+ *
+ *   v   = x[i] + (b ? b[channel(i)] : 0)
+ *   y   = (grad == 0) ?  (v   > 0 ? v : v * alpha) * scale            -- act=3, grad=0  (forward)
+ *       : (grad == 1) ?  (ref > 0 ? v : v * alpha) * scale            -- act=3, grad=1  (backward / grad-grad)
+ *       :                0                                            -- grad == 2
+ *   act == 1 is the linear variant (y = v * scale; 0 for grad == 2).
+ *
+ * `n` = total elements, `C` = channels, `inner` = product of dims after the channel dim (NCHW only; a
+ * [B,C] matrix is inner = 1).  `ref` is required iff grad == 1.  `bias_grad` (optional, grad == 1 only):
+ * if non-NULL it must be a ZEROED float[C]; the kernel adds sum over (n,h,w) of y into it, fusing the
+ * reference's separate grad_input.sum(dim) pass (fused_act.py:33-38).
+ * ---------------------------------------------------------------------------------------------- */
+int ideas_fused_bias_act(void* y, const void* x, const void* b, const void* ref, float* bias_grad,
+                         int64_t n, int C, int64_t inner, int layout,
+                         int act, int grad, float alpha, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * upfirdn2d.  Replaces upfirdn2d_op (upfirdn2d_kernel.cu:209-368): zero-stuff by `up`, pad (negative pad
+ * crops), correlate with the FLIPPED kh x kw FIR, decimate by `down`.  x is [B,C,in_h,in_w] (NCHW) or
+ * [B,in_h,in_w,C] (NHWC); y has out = (in*up + pad0 + pad1 - k) / down + 1 per axis.  `fir` is a device
+ * float[kh*kw], row-major, kh,kw <= 8.  `gain` multiplies the FIR (1.0f for the plain op).
+ * The gradient is the same call with up<->down swapped, the FIR flipped and
+ * pads (k - p0 - 1, in*up - out*down + p0 - up + 1)  (upfirdn2d.py:111-114).
+ * ---------------------------------------------------------------------------------------------- */
+int ideas_upfirdn2d(void* y, const void* x, const float* fir,
+                    int B, int C, int in_h, int in_w, int out_h, int out_w,
+                    int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                    int pad_x0, int pad_y0, float gain, int flip,
+                    int layout, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32), NHWC.
+ * Replaces the cuDNN calls behind F.conv2d / F.conv_transpose2d (stylegan2/model.py:115-121,258,273;
+ * models.py:32-38) and, with in_scale/out_scale, the per-sample weight materialisation of
+ * ModulatedConv2d (stylegan2/model.py:240-248):  y[b,:,:,o] = out_scale[b,o] * sum w[o,t,i] * in_scale[b,i] * x[b,..,i].
+ *
+ * One launch computes, for every point (b, oy, ox) of a logical OH x OW grid and every output channel o:
+ *     acc = sum over taps (ty,tx) in [0,TY)x[0,TX) and ci in [0,Cin) of
+ *              wmat[o][(ty*TX+tx)*Cin + ci] * X(b, oy*sy + ty*dy + offy, ox*sx + tx*dx + offx, ci)
+ *     where X(...) is 0 outside [0,IH)x[0,IW) (or mirrored, reflect=1), times in_scale[b*Cin+ci] if given;
+ *     y[b, oy*osy + ooy, ox*osx + oox, o] = epilogue(acc)
+ * The output tensor is [B, YH, YW, Cout].  This one parameterisation covers forward convs (sy = stride,
+ * dy = 1, off = -pad), input gradients of stride-1 convs (flipped/transposed wmat), and the four parity
+ * phases of stride-2 transposed convs / stride-2 input gradients (osy = 2, ooy = phase).
+ *
+ * epilogue(acc): v = acc * gain * (out_scale ? out_scale[b*Cout+o] : 1) + (bias ? bias[o] : 0);
+ *                if act: v = (v > 0 ? v : v*alpha) * act_gain;
+ *                if resid: v = (v + resid[same index as y]) * resid_gain;
+ *                if accumulate: y += v else y = v.
+ * Requires Cin % 4 == 0 and 16-byte aligned x / wmat.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ideas_conv_params {
+    int B, IH, IW, Cin;          /* input  [B,IH,IW,Cin]                    */
+    int YH, YW, Cout;            /* output tensor [B,YH,YW,Cout]            */
+    int OH, OW;                  /* logical grid computed by this launch    */
+    int TY, TX;                  /* taps                                    */
+    int sy, sx, dy, dx, offy, offx;
+    int osy, osx, ooy, oox;      /* output placement                        */
+    int reflect;                 /* 1 = mirror out-of-range input coords    */
+    int act;                     /* 1 = leaky-ReLU epilogue                 */
+    float alpha, act_gain, resid_gain;
+    int accumulate;
+    float gain;                  /* uniform multiplier on the accumulator (equalised-lr weight scale) */
+} ideas_conv_params;
+
+int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
+                     const float* bias, const void* resid, const ideas_conv_params* p, int dtype, void* stream);
+
+/* Weight gradient of the same family:  for every o, tap, ci
+ *     gw[o][(ty*TX+tx)*Cin + ci] (+)= sum over (b,oy,ox) of  G(b,oy,ox,o) * X(b, iy, ix, ci)
+ * with G = gy[b, oy*osy+ooy, ox*osx+oox, o] * (out_scale ? out_scale[b*Cout+o] : 1),
+ *      X as above (zero / reflect outside, times in_scale).  gw must be ZEROED by the caller unless it is
+ * meant to accumulate; split-K partial sums (times `gain`) are added with float atomics (order not
+ * deterministic).
+ * Requires Cin % 4 == 0 and Cout % 4 == 0.
+ */
+int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                     const ideas_conv_params* p, int dtype, void* stream);
+
+/* Generic direct convolution (VALU) with the same parameterisation and epilogue; any Cin/Cout. Used for the
+ * handful of tiny-K layers (RGB / N-channel inputs) where the MFMA tile would be empty. */
+int ideas_conv_direct(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
+                      const float* bias, const void* resid, const ideas_conv_params* p, int dtype, void* stream);
+int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                            const ideas_conv_params* p, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Style demodulation (stylegan2/model.py:243-244):  d[b,o] = rsqrt( sum_i s[b,i]^2 * wsq[o,i] + eps )
+ * where wsq[o,i] = scale^2 * sum_k W[o,i,k]^2.  One wavefront per (b,o), shuffle reduction over Cin.
+ * ---------------------------------------------------------------------------------------------- */
+int ideas_demod(float* d, const float* s, const float* wsq, int B, int Cin, int Cout, float eps, void* stream);
+
+/* Per-(b,c) sum over pixels of a[b,p,c]*g[b,p,c] (NHWC).  Gives d(style) and d(demod) of the modulated conv
+ * without materialising per-sample weights.  out must be ZEROED float[B*C]. */
+int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, int C, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDEAS_HIP_H */

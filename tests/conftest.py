@@ -1,0 +1,60 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    def t(self, k, device="cpu"):
+        return torch.from_numpy(np.array(self.z[k])).to(device)
+
+    def json(self, k):
+        return json.loads(str(self.z[k]))
+
+    def keys(self):
+        return self.z.files
+
+
+@pytest.fixture(scope="session")
+def ops_golden():
+    return Golden("ops.npz")
+
+
+@pytest.fixture(scope="session")
+def nets_golden():
+    return Golden("nets_tiny.npz")
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| — the tolerance form stated in DESIGN.md."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    denom = float(b.abs().max())
+    return float((a - b).abs().max()) / (denom if denom > 0 else 1.0)

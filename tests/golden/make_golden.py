@@ -1,0 +1,564 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own Python on CPU.
+
+Runs only in the build container (needs /root/reference).  Nothing from the reference is copied:
+the script imports it, feeds seeded inputs, and stores inputs / outputs / gradients as .npz data.
+The import recipe is SURVEY.md Appendix B (stub the import-time JIT of the CUDA ops; the CPU
+branches of the ops never touch the extension objects).
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py ops nets   # a subset
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("IDEAS_REFERENCE", "/root/reference")
+
+
+def import_reference():
+    import torch.utils.cpp_extension as ce
+    ce.load = lambda *a, **k: types.SimpleNamespace()
+    sys.path.insert(0, REF)
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.utils = types.ModuleType("torchvision.utils")
+    tv.utils.save_image = lambda *a, **k: None
+    sys.modules.update({
+        "torchvision": tv, "torchvision.transforms": tv.transforms, "torchvision.utils": tv.utils,
+        "lmdb": types.ModuleType("lmdb"), "imutils": types.ModuleType("imutils"),
+        "imutils.paths": types.ModuleType("imutils.paths"),
+    })
+    sys.modules["imutils.paths"].list_files = lambda p: []
+    import models as RM           # noqa
+    import utils as RU            # noqa
+    import stylegan2.model as RL  # noqa
+    import stylegan2.op as RO     # noqa
+    return RM, RU, RL, RO
+
+
+class Shrink(int):
+    """An int-like ``channel_multiplier`` standing for 1/den: ``256 * Shrink(8) == 32``.
+
+    ImageLevelDiscriminator multiplies a width table by ``channel_multiplier`` (models.py:341-345);
+    this lets the unmodified reference build a narrow Dreal so the step fixtures replay in seconds.
+    """
+    def __new__(cls, den):
+        o = super().__new__(cls, 1)
+        o.den = den
+        return o
+
+    def __rmul__(self, other):
+        return int(other) // self.den
+
+    __mul__ = __rmul__
+
+
+def ns(**kw):
+    return argparse.Namespace(**kw)
+
+
+def tiny_args(image_size, cm_den=8, N=1):
+    return ns(channel=4, structure_channel=8, texture_channel=64, N=N, image_size=image_size,
+              channel_multiplier=Shrink(cm_den), blur_kernel=(1, 3, 3, 1))
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------------
+def gen_ops(RM, RU, RL, RO):
+    out = {}
+    g = torch.Generator().manual_seed(1)
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+
+    # known answers quoted in SURVEY.md §8(a)
+    out["ka.make_kernel"] = npy(RL.make_kernel((1, 3, 3, 1)))
+    out["ka.flr.x"] = np.array([[-1.0, 0.0, 2.0]], np.float32)
+    out["ka.flr.b"] = np.array([0.5, 0.0, -3.0], np.float32)
+    out["ka.flr.y"] = npy(RO.fused_leaky_relu(torch.tensor(out["ka.flr.x"]), torch.tensor(out["ka.flr.b"])))
+
+    # fused_leaky_relu: 4-D and 2-D, forward + grad + grad-grad (via autograd of the CPU branch)
+    for tag, shape in (("flr4", (2, 5, 7, 6)), ("flr2", (3, 9))):
+        x = rn(*shape).requires_grad_(True)
+        b = rn(shape[1]).requires_grad_(True)
+        y = RO.fused_leaky_relu(x, b)
+        gy = rn(*shape).requires_grad_(True)
+        gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+        ggx, ggb = rn(*shape), rn(shape[1])
+        (ggy,) = torch.autograd.grad((gx * ggx).sum() + (gb * ggb).sum(), gy)
+        out.update({f"{tag}.x": npy(x), f"{tag}.b": npy(b), f"{tag}.y": npy(y), f"{tag}.gy": npy(gy),
+                    f"{tag}.gx": npy(gx), f"{tag}.gb": npy(gb), f"{tag}.ggx": npy(ggx), f"{tag}.ggb": npy(ggb),
+                    f"{tag}.ggy": npy(ggy)})
+
+    # blur: the four variants on the path, odd/even/tiny sizes, + generic up/down cases
+    k1 = RL.make_kernel((1, 3, 3, 1))
+    cases = []
+    for hw in ((1, 1), (2, 3), (4, 4), (5, 8), (9, 9), (16, 17), (33, 31)):
+        for pad, gain in (((2, 2), 1), ((1, 1), 1), ((1, 1), 4), ((2, 1), 1)):
+            cases.append((hw, pad, gain, 1, 1))
+    cases += [((6, 5), (2, 1), 4, 2, 1), ((8, 8), (1, 1), 1, 1, 2), ((7, 9), (0, 0), 1, 1, 1), ((5, 5), (3, 2), 1, 2, 2)]
+    meta = []
+    for ci, (hw, pad, gain, up, down) in enumerate(cases):
+        if up == 1 and hw[0] + pad[0] + pad[1] < 4:
+            continue
+        x = rn(2, 3, *hw).requires_grad_(True)
+        k = k1 * gain
+        y = RO.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        gy = rn(*y.shape)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        out[f"blur{ci}.x"], out[f"blur{ci}.y"], out[f"blur{ci}.gy"], out[f"blur{ci}.gx"] = npy(x), npy(y), npy(gy), npy(gx)
+        meta.append(dict(i=ci, pad=list(pad), gain=gain, up=up, down=down))
+    out["blur.delta22"] = npy(RO.upfirdn2d(torch.eye(16)[5].view(1, 1, 4, 4), k1, pad=(2, 2)))
+    out["blur.delta11"] = npy(RO.upfirdn2d(torch.eye(16)[5].view(1, 1, 4, 4), k1, pad=(1, 1)))
+
+    # asymmetric FIR (flip semantics) — not on the path but part of the op's contract
+    ka = torch.tensor([[1., 2., 0.], [0., -1., 3.]])
+    x = rn(1, 2, 6, 7)
+    out["blurasym.x"], out["blurasym.k"] = npy(x), npy(ka)
+    out["blurasym.y"] = npy(RO.upfirdn2d(x, ka, pad=(1, 1)))
+
+    # EqualConv2d combos on the path
+    conv_meta = []
+    for ci, (cin, cout, k, s, p, hw, bias) in enumerate((
+            (3, 8, 1, 1, 0, 9, False), (8, 12, 3, 1, 1, 10, False), (8, 12, 3, 1, 0, 12, False),
+            (8, 16, 3, 2, 0, 13, False), (8, 16, 1, 2, 0, 11, False), (12, 6, 2, 1, 0, 2, False),
+            (16, 3, 1, 1, 0, 8, True))):
+        torch.manual_seed(100 + ci)
+        m = RL.EqualConv2d(cin, cout, k, stride=s, padding=p, bias=bias)
+        if bias:
+            m.bias.data.normal_()
+        x = rn(2, cin, hw, hw).requires_grad_(True)
+        y = m(x)
+        gy = rn(*y.shape)
+        grads = torch.autograd.grad(y, [x] + list(m.parameters()), gy)
+        out[f"conv{ci}.x"], out[f"conv{ci}.w"], out[f"conv{ci}.y"], out[f"conv{ci}.gy"] = npy(x), npy(m.weight), npy(y), npy(gy)
+        out[f"conv{ci}.gx"], out[f"conv{ci}.gw"] = npy(grads[0]), npy(grads[1])
+        if bias:
+            out[f"conv{ci}.b"], out[f"conv{ci}.gb"] = npy(m.bias), npy(grads[2])
+        conv_meta.append(dict(i=ci, cin=cin, cout=cout, k=k, stride=s, padding=p, bias=bias))
+
+    # EqualConvTranspose2d k=1 s=2 (skip branch of the upsampling StyledResBlock)
+    torch.manual_seed(200)
+    m = RM.EqualConvTranspose2d(8, 6, 1, stride=2, padding=0, bias=False)
+    x = rn(2, 8, 5, 5).requires_grad_(True)
+    y = m(x)
+    gy = rn(*y.shape)
+    gx, gw = torch.autograd.grad(y, (x, m.weight), gy)
+    out.update({"convT.x": npy(x), "convT.w": npy(m.weight), "convT.y": npy(y), "convT.gy": npy(gy), "convT.gx": npy(gx), "convT.gw": npy(gw)})
+
+    # EqualLinear (plain, activated, bias_init=1)
+    for tag, kw in (("lin", {}), ("linact", {"activation": "fused_lrelu"}), ("linmod", {"bias_init": 1})):
+        torch.manual_seed(300)
+        m = RL.EqualLinear(10, 7, **kw)
+        x = rn(4, 10).requires_grad_(True)
+        y = m(x)
+        gy = rn(*y.shape)
+        gx, gw, gb = torch.autograd.grad(y, (x, m.weight, m.bias), gy)
+        out.update({f"{tag}.x": npy(x), f"{tag}.w": npy(m.weight), f"{tag}.b": npy(m.bias), f"{tag}.y": npy(y),
+                    f"{tag}.gy": npy(gy), f"{tag}.gx": npy(gx), f"{tag}.gw": npy(gw), f"{tag}.gb": npy(gb)})
+
+    # ModulatedConv2d same-res and upsample, Cin in {8, 32}
+    mod_meta = []
+    for ci, (cin, cout, up, hw) in enumerate(((8, 12, False, 6), (32, 16, False, 8), (8, 12, True, 5), (32, 16, True, 8))):
+        torch.manual_seed(400 + ci)
+        m = RL.ModulatedConv2d(cin, cout, 3, 24, upsample=up, blur_kernel=[1, 3, 3, 1])
+        x = rn(3, cin, hw, hw).requires_grad_(True)
+        st = rn(3, 24).requires_grad_(True)
+        y = m(x, st)
+        gy = rn(*y.shape)
+        gx, gs, gw, gmw, gmb = torch.autograd.grad(y, (x, st, m.weight, m.modulation.weight, m.modulation.bias), gy)
+        out.update({f"mod{ci}.x": npy(x), f"mod{ci}.style": npy(st), f"mod{ci}.w": npy(m.weight),
+                    f"mod{ci}.mw": npy(m.modulation.weight), f"mod{ci}.mb": npy(m.modulation.bias),
+                    f"mod{ci}.y": npy(y), f"mod{ci}.gy": npy(gy), f"mod{ci}.gx": npy(gx), f"mod{ci}.gstyle": npy(gs),
+                    f"mod{ci}.gw": npy(gw), f"mod{ci}.gmw": npy(gmw), f"mod{ci}.gmb": npy(gmb)})
+        mod_meta.append(dict(i=ci, cin=cin, cout=cout, up=up))
+
+    # message codec round trips (utils.py:74-97)
+    codec = []
+    for sigma in (1, 2, 3):
+        for delta in (0.0, 0.25, 0.5):
+            torch.manual_seed(500 + sigma * 10 + int(delta * 100))
+            M = torch.randint(0, 2, (3, 12 * sigma), dtype=torch.float)
+            torch.manual_seed(7)
+            jitter = torch.rand(3, 12)
+            torch.manual_seed(7)
+            Z = RU.message_to_tensor(M, sigma, delta)
+            Mh = RU.tensor_to_message(Z, sigma)
+            key = f"codec.s{sigma}.d{int(delta * 100)}"
+            out[key + ".M"], out[key + ".jitter"], out[key + ".Z"], out[key + ".Mh"] = npy(M), npy(jitter), npy(Z), npy(Mh)
+            codec.append(dict(sigma=sigma, delta=delta, key=key))
+
+    # patchify: boxes -> patches
+    torch.manual_seed(11)
+    random.seed(11)
+    img = rn(2, 3, 64, 64)
+    rec = BoxRecorder()
+    with rec:
+        patches = RU.patchify_image(img, 3)
+    out["patch.img"], out["patch.out"], out["patch.boxes"] = npy(img), npy(patches), np.array(rec.calls[0], np.int64)
+
+    out["meta"] = np.array(json.dumps(dict(blur=meta, conv=conv_meta, mod=mod_meta, codec=codec)))
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
+    print("ops.npz", len(out), "arrays")
+
+
+class BoxRecorder:
+    """Records the crop boxes drawn inside utils.patchify_image (utils.py:128-139)."""
+    def __init__(self):
+        self.calls = []
+        self._sizes = None
+        self._pos = []
+
+    def __enter__(self):
+        self._rand, self._rr = torch.rand, random.randrange
+        rec = self
+
+        def rand(*a, **k):
+            r = rec._rand(*a, **k)
+            if len(a) == 1 and isinstance(a[0], int) and not k:
+                rec._flush()
+                rec._sizes = r.clone()
+            return r
+
+        def randrange(*a, **k):
+            v = rec._rr(*a, **k)
+            rec._pos.append((v, a[1]))
+            return v
+        torch.rand, random.randrange = rand, randrange
+        return self
+
+    def _flush(self):
+        if self._sizes is not None and self._pos:
+            n = len(self._pos) // 2
+            boxes = []
+            for i in range(n):
+                (y, hy), (x, wx) = self._pos[2 * i], self._pos[2 * i + 1]
+                boxes.append((y, x, self._H - hy, self._W - wx))
+            self.calls.append(boxes)
+        self._sizes, self._pos = None, []
+
+    _H = _W = 64
+
+    def __exit__(self, *exc):
+        self._flush()
+        torch.rand, random.randrange = self._rand, self._rr
+
+
+# --------------------------------------------------------------------------------------------
+NET_CLASSES = {
+    "E": "DisentanglementEncoder", "G": "Generator", "Gstru": "StructureGenerator", "Ex": "TensorExtractor",
+    "Dreal": "ImageLevelDiscriminator", "Dco": "CooccurenceDiscriminator", "Ddist": "DistributionDiscriminator",
+}
+
+
+def gen_nets(RM, RU, RL, RO):
+    """Tiny-width networks at R=64, B=2: state dicts + inputs + outputs + grads."""
+    args = tiny_args(64)
+    out = {}
+    g = torch.Generator().manual_seed(2)
+
+    def rn(*s):
+        return torch.randn(*s, generator=g)
+
+    def perturb(net):  # biases are zero-initialised; make them matter
+        for n_, p in net.named_parameters():
+            if n_.endswith("bias"):
+                p.data.add_(0.1 * torch.randn(p.shape, generator=g))
+
+    def sd(tag, net, store=True):
+        if store:
+            for k, v in net.state_dict().items():
+                out[f"{tag}/sd/{k}"] = npy(v)
+        out[f"{tag}/keys"] = np.array(json.dumps([[k, list(v.shape)] for k, v in net.state_dict().items()]))
+
+    def run(tag, net, inputs, fwd=None, store=True, r1_input=None):
+        perturb(net)
+        sd(tag, net, store)
+        xs = [x.clone().requires_grad_(True) for x in inputs]
+        ys = (fwd or net)(*xs)
+        ys = ys if isinstance(ys, tuple) else (ys,)
+        ws = [rn(*y.shape) for y in ys]
+        loss = sum((y * w).sum() for y, w in zip(ys, ws))
+        params = [p for p in net.parameters()]
+        grads = torch.autograd.grad(loss, xs + params, allow_unused=True)
+        for i, x in enumerate(inputs):
+            out[f"{tag}/in{i}"] = npy(x)
+            out[f"{tag}/gin{i}"] = npy(grads[i])
+        for i, (y, w) in enumerate(zip(ys, ws)):
+            out[f"{tag}/out{i}"], out[f"{tag}/w{i}"] = npy(y), npy(w)
+        out[f"{tag}/gparam_norms"] = np.array([0.0 if gp is None else float(gp.norm()) for gp in grads[len(xs):]], np.float64)
+        if r1_input is not None:
+            x = inputs[r1_input].clone().requires_grad_(True)
+            xs2 = [x if i == r1_input else t for i, t in enumerate(inputs)]
+            pred = (fwd or net)(*xs2)
+            pred = pred[0] if isinstance(pred, tuple) else pred
+            r1 = RU.d_r1_loss(pred, x)
+            gr = torch.autograd.grad(r1, params, allow_unused=True)
+            out[f"{tag}/r1"] = npy(r1)
+            out[f"{tag}/r1_gparam_norms"] = np.array([0.0 if gp is None else float(gp.norm()) for gp in gr], np.float64)
+
+    B = 2
+    torch.manual_seed(10); E = RM.init_model("DisentanglementEncoder", args)
+    run("E", E, [rn(B, 3, 64, 64)])
+    torch.manual_seed(11); G = RM.init_model("Generator", args)
+    run("G", G, [rn(B, 8, 4, 4), rn(B, 64)])
+    torch.manual_seed(12); Gs = RM.init_model("StructureGenerator", args)
+    run("Gstru", Gs, [rn(B, 1, 4, 4)])
+    torch.manual_seed(13); Ex = RM.init_model("TensorExtractor", args)
+    run("Ex", Ex, [rn(B, 8, 4, 4)])
+    torch.manual_seed(14); Dd = RM.init_model("DistributionDiscriminator", args)
+    run("Ddist", Dd, [rn(B, 64)], r1_input=0)
+    # Dco needs 64x64 patches and size<=511 -> build with image_size=256
+    a256 = tiny_args(256)
+    torch.manual_seed(15); Dc = RM.init_model("CooccurenceDiscriminator", a256)
+    run("Dco", Dc, [rn(B, 3, 64, 64), rn(B * 2, 3, 64, 64)], fwd=lambda a, r: Dc(a, r, ref_batch=2)[0], r1_input=0)
+    # Dreal: fixed 512-wide tail -> weights are regenerated from the seed, not stored
+    torch.manual_seed(16); Dr = RM.init_model("ImageLevelDiscriminator", args)
+    out["Dreal/seed"] = np.array(16)
+    g = torch.Generator().manual_seed(3)
+    run("Dreal", Dr, [rn(B, 3, 64, 64)], store=False, r1_input=0)
+    # N=2 variants change only Gstru.structure.0.0 and Ex.extract.4.* 
+    a2 = tiny_args(64, N=2)
+    torch.manual_seed(17); Gs2 = RM.init_model("StructureGenerator", a2)
+    run("Gstru_N2", Gs2, [rn(B, 2, 4, 4)])
+    torch.manual_seed(18); Ex2 = RM.init_model("TensorExtractor", a2)
+    run("Ex_N2", Ex2, [rn(B, 8, 4, 4)])
+    np.savez_compressed(os.path.join(HERE, "nets_tiny.npz"), **out)
+    print("nets_tiny.npz", len(out), "arrays", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+
+def gen_init(RM, RU, RL, RO):
+    """Seeded-init checksums at FULL width: pins parameter-creation order and state-dict keys."""
+    full = ns(channel=32, structure_channel=8, texture_channel=2048, N=1, image_size=256,
+              channel_multiplier=1, blur_kernel=(1, 3, 3, 1))
+    res = {}
+    for tag, cls in NET_CLASSES.items():
+        torch.manual_seed(1234)
+        net = RM.init_model(cls, full)
+        sd = net.state_dict()
+        res[tag] = dict(
+            n_params=sum(p.numel() for p in net.parameters()),
+            keys=[[k, list(v.shape)] for k, v in sd.items()],
+            param_keys=[k for k, _ in net.named_parameters()],
+            sums={k: float(v.double().sum()) for k, v in list(sd.items())[:: max(1, len(sd) // 12)]},
+            total_sum=float(sum(v.double().sum() for v in sd.values())),
+            total_abs=float(sum(v.double().abs().sum() for v in sd.values())),
+        )
+        print(tag, res[tag]["n_params"])
+    with open(os.path.join(HERE, "init_checksums.json"), "w") as f:
+        json.dump(res, f)
+
+
+# --------------------------------------------------------------------------------------------
+class ZeroDco(torch.nn.Module):
+    """Stand-in for Dco below R=256, where the reference's own Dco cannot run on 16x16 / 32x32 patches
+    (models.py:400 collapses).  Zero logits that still depend on the input, so the
+    unmodified train() — including its R1 branch — runs; every Dco term then has zero gradient."""
+    def __init__(self):
+        super().__init__()
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, input, reference=None, ref_batch=None, ref_input=None):
+        o = input.flatten(1).sum(1, keepdim=True) * 0 + self.dummy * 0
+        return o, o
+
+
+class SpyOptim:
+    def __init__(self, opt, name, log):
+        self.opt, self.name, self.log = opt, name, log
+
+    def zero_grad(self):
+        self.opt.zero_grad()
+
+    def step(self):
+        norms = []
+        for grp in self.opt.param_groups:
+            for p in grp["params"]:
+                norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+        self.log.append((self.name, norms))
+        self.opt.step()
+
+    def state_dict(self):
+        return self.opt.state_dict()
+
+
+def run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco):
+    """Drive the reference's UNMODIFIED train() (train.py:21-322) and capture everything the step consumes/produces."""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import train as T
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    os.makedirs("exp/samples"); os.makedirs("exp/checkpoints")
+    T.base_dir, T.sample_dir, T.ckpt_dir = "exp", "exp/samples", "exp/checkpoints"
+    torch.manual_seed(seed)
+    names = ["E", "G", "Gstru", "Ex", "Dreal", "Dco", "Ddist"]
+    trainer = {}
+    for n_ in names:
+        trainer[n_] = ZeroDco() if (n_ == "Dco" and zero_dco) else RM.init_model(NET_CLASSES[n_], args)
+    for n_ in ("E", "G", "Gstru", "Ex"):
+        trainer[n_ + "_ema"] = RM.init_model(NET_CLASSES[n_], args).eval()
+        RU.accumulate(trainer[n_ + "_ema"], trainer[n_], 0)
+    log = []
+    r = args.d_reg_every / (args.d_reg_every + 1)
+    trainer["g_optim"] = SpyOptim(torch.optim.Adam(
+        list(trainer["E"].parameters()) + list(trainer["G"].parameters()) + list(trainer["Gstru"].parameters()),
+        lr=args.lr, betas=(0.0, 0.99)), "g", log)
+    trainer["ex_optim"] = SpyOptim(torch.optim.Adam(trainer["Ex"].parameters(), lr=args.lr, betas=(0.0, 0.99)), "ex", log)
+    trainer["d_optim"] = SpyOptim(torch.optim.Adam(
+        list(trainer["Dreal"].parameters()) + list(trainer["Dco"].parameters()) + list(trainer["Ddist"].parameters()),
+        lr=args.lr * r, betas=(0.0 ** r, 0.99 ** r)), "d", log)
+
+    # record the random draws: Z (torch.rand size=...), T2 (torch.rand_like), boxes (patchify_image)
+    draws = {"Z": [], "T2": [], "boxes": [], "M": [], "jitter": []}
+    o_rand, o_rand_like, o_randint, o_patch = torch.rand, torch.rand_like, torch.randint, T.patchify_image
+    in_codec = [False]
+
+    def rand(*a, **k):
+        r_ = o_rand(*a, **k)
+        if "size" in k:
+            draws["Z"].append(r_.clone())
+        return r_
+
+    def rand_like(t, **k):
+        r_ = o_rand_like(t, **k)
+        (draws["jitter"] if in_codec[0] else draws["T2"]).append(r_.clone())
+        return r_
+
+    def randint(*a, **k):
+        r_ = o_randint(*a, **k)
+        draws["M"].append(r_.clone())
+        return r_
+
+    def patch(img, n_crop, *a, **k):
+        rec = BoxRecorder()
+        rec._H, rec._W = img.shape[2], img.shape[3]
+        torch.rand = o_rand
+        with rec:
+            p = o_patch(img, n_crop, *a, **k)
+        torch.rand = rand
+        draws["boxes"].append(rec.calls[0])
+        return p
+
+    o_m2t = T.message_to_tensor
+
+    def m2t(*a, **k):
+        in_codec[0] = True
+        try:
+            return o_m2t(*a, **k)
+        finally:
+            in_codec[0] = False
+
+    losses_per_iter = []
+    o_accum = T.accumulate
+    snap = {}
+
+    torch.rand, torch.rand_like, torch.randint, T.patchify_image, T.message_to_tensor = rand, rand_like, randint, patch, m2t
+    # capture the loss_dict at the end of every iteration through the first EMA accumulate call
+    count = [0]
+
+    import inspect
+
+    def accumulate(m1, m2, decay=0.999):
+        if m1 is trainer["E_ema"]:
+            fr = inspect.currentframe().f_back
+            ld = fr.f_locals["loss_dict"]
+            rec_ = {k: float(v) for k, v in ld.items()}
+            rec_["Loss_total"] = float(fr.f_locals["Loss_total"])
+            rec_["hat_Z"] = fr.f_locals["hat_Z"].detach().clone()
+            losses_per_iter.append(rec_)
+        return o_accum(m1, m2, decay)
+    T.accumulate = accumulate
+    test_lines = []
+    o_print = print
+
+    import builtins
+
+    def spy_print(*a, **k):
+        if a and isinstance(a[0], str) and a[0].startswith("[Testing"):
+            test_lines.append(a[0])
+        o_print(*a, **k)
+    builtins.print = spy_print
+    try:
+        torch.manual_seed(seed + 1)
+        random.seed(seed + 1)
+        T.train(exp_name="exp", args=args, loader=[X], trainer=trainer, device="cpu")
+    finally:
+        torch.rand, torch.rand_like, torch.randint, T.patchify_image, T.message_to_tensor = o_rand, o_rand_like, o_randint, o_patch, o_m2t
+        T.accumulate = o_accum
+        builtins.print = o_print
+        os.chdir(cwd)
+    return trainer, draws, log, losses_per_iter, test_lines
+
+
+def gen_step(RM, RU, RL, RO, which):
+    if which == "r64":
+        R, B, n_iters, zero_dco = 64, 2, 2, True
+    else:
+        R, B, n_iters, zero_dco = 256, 1, 2, False
+    args = tiny_args(R)
+    args.__dict__.update(num_iters=n_iters, start_iter=0, lambda_Ex=10.0, lr=0.002, batch_size=B, real_r1=10.0,
+                         texture_r1=1.0, dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=2,
+                         log_every=1, show_every=n_iters, save_every=10 ** 9)
+    seed = 77 if which == "r64" else 78
+    gx = torch.Generator().manual_seed(seed + 100)
+    X = torch.rand(B, 3, R, R, generator=gx) * 2 - 1
+    trainer, draws, log, losses, test_lines = run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco)
+    out = {"X": npy(X), "seed": np.array(seed)}
+    out["meta"] = np.array(json.dumps(dict(R=R, B=B, n_iters=n_iters, zero_dco=zero_dco, d_reg_every=2, channel=4,
+                                           texture_channel=64, cm_den=8, test_lines=test_lines,
+                                           opt_log=[[n_, len(v)] for n_, v in log])))
+    for i, z in enumerate(draws["Z"]):
+        out[f"Z{i}"] = npy(z)          # raw U[0,1) draws; the step uses z*2-1
+    for i, t in enumerate(draws["T2"]):
+        out[f"T2_{i}"] = npy(t)
+    for i, b in enumerate(draws["boxes"]):
+        out[f"boxes{i}"] = np.array(b, np.int64)
+    for i, m in enumerate(draws["M"]):
+        out[f"M{i}"] = npy(m)
+    for i, j in enumerate(draws["jitter"]):
+        out[f"jitter{i}"] = npy(j)
+    for i, (n_, norms) in enumerate(log):
+        out[f"opt{i}.{n_}.gradnorms"] = np.array(norms, np.float64)
+    for i, ld in enumerate(losses):
+        hz = ld.pop("hat_Z")
+        out[f"hatZ{i}"] = npy(hz)
+        out[f"losses{i}"] = np.array(json.dumps(ld))
+    # parameter checksums after the last step (per net: sum and abs-sum in float64)
+    cks = {}
+    for n_ in ("E", "G", "Gstru", "Ex", "Dreal", "Dco", "Ddist", "E_ema", "G_ema", "Gstru_ema", "Ex_ema"):
+        ps = list(trainer[n_].parameters())
+        cks[n_] = [float(sum(p.double().sum() for p in ps)), float(sum(p.double().abs().sum() for p in ps))]
+    out["final_checksums"] = np.array(json.dumps(cks))
+    np.savez_compressed(os.path.join(HERE, f"step_{which}.npz"), **out)
+    print(f"step_{which}.npz", len(out), "arrays;", test_lines)
+    for ld in losses:
+        print(ld)
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ["ops", "nets", "init", "step_r64", "step_r256"]
+    mods = import_reference()
+    torch.set_num_threads(8)
+    if "ops" in todo:
+        gen_ops(*mods)
+    if "nets" in todo:
+        gen_nets(*mods)
+    if "init" in todo:
+        gen_init(*mods)
+    if "step_r64" in todo:
+        gen_step(*mods, "r64")
+    if "step_r256" in todo:
+        gen_step(*mods, "r256")
