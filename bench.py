@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""IDEAS headline benchmark: train images/sec of the full G+D+Ex iteration at 256x256 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of train.py:48-221 (D phase, lazy R1 when iter % 16 == 0, G phase, Ex step, EMA)
+on a synthetic batch already resident in HBM.  Workload: BASELINE.json configs[2] — N=1, sigma=1, 256x256,
+batch 32 per GPU, full-width networks (channel 32, texture 2048), f32, through the HIP kernels of
+libideas_hip.so.  Weak scaling: every rank owns its own 32-image shard; gradients are averaged with one RCCL
+all-reduce per optimiser group (ideas_amd/ddp.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# forward GFLOP per sample at R=256, full width (measured by hooks on the reference)
+F_E, F_G, F_GS, F_EX, F_DR, F_DC = 16.52, 95.99, 0.21, 0.19, 53.26, 1.00
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def flop_per_image(elided: bool, d_reg_every: int = 16) -> float:
+    """Algorithmic GFLOP per image per iteration at R=256 (rule: bwd with weight+input grads = 2F, input-only = 1F)."""
+    d_phase = (F_E + F_GS + 3 * F_G + 4 * F_DR + 48 * F_DC) + 2 * (4 * F_DR + 48 * F_DC)
+    g_fwd = 2 * F_E + F_GS + 3 * F_G + 3 * F_DR + 40 * F_DC + F_EX
+    g_bwd = 2 * (2 * F_E + F_GS + 3 * F_G + F_EX) + 3 * F_DR + 8 * F_DC
+    second = 0.0 if elided else 2 * (F_EX + F_E + F_G + F_GS) + 2 * F_E
+    r1 = 6 * (F_DR + 40 * F_DC) / d_reg_every
+    return d_phase + g_fwd + g_bwd + second + r1
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=16)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--batch", type=int, default=32, help="images per GPU")
+    p.add_argument("--image-size", type=int, default=256)
+    p.add_argument("--N", type=int, default=1)
+    p.add_argument("--literal-second-backward", action="store_true",
+                   help="re-traverse Ex->E->G->Gstru for the Ex gradient exactly like train.py:214-215")
+    p.add_argument("--cpu-baseline", choices=["auto", "skip"], default="auto")
+    p.add_argument("--roofline", choices=["on", "off", "only"], default="on")
+    p.add_argument("--roofline-launches", type=int, default=20)
+    return p.parse_args()
+
+
+def roofline_probe(device, batch: int, launches: int):
+    """Dominant kernel = the f32-MFMA implicit GEMM (conv_igemm_kernel<2,2,2,2>) on its heaviest instance,
+    G.layers.7.conv2: modulated 3x3, 128 -> 128 channels at 256x256 (19.33 GFLOP per sample).
+    Timed with HIP events on the launch stream over `launches` back-to-back launches."""
+    from ideas_amd.op.conv import conv_fwd_raw
+    from ideas_amd.op.conv_plan import ConvGeom
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(batch, 128, 256, 256, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(128, 128, 3, 3, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+    s = (torch.randn(batch, 128, generator=g) * 0.5 + 1).to(device)
+    d = (torch.rand(batch, 128, generator=g) + 0.5).to(device)
+    geom = ConvGeom(3, 3, 1, 1, False)
+    for _ in range(3):
+        conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel<2,2,2,2> (G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d)" % batch,
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline():
+    """The oracle's step (oracle/torch_ref.py, the CPU restatement pinned to the reference) on the host cores.
+    Bounded sample: ONE full-width iteration without the R1 branch at batch 1 — 256x256 with Dco when the host has
+    >= 32 hardware threads, else the 64x64 Dco-less sub-step (BASELINE.json configs[0])."""
+    import oracle.torch_ref as O
+    from ideas_amd.models import init_model
+    from ideas_amd import train_step as TS
+    cores = os.cpu_count() or 1
+    big = cores >= 32
+    R = 256 if big else 64
+    torch.set_num_threads(cores)
+    args = TS.default_args(image_size=R, use_dco=big)
+    torch.manual_seed(0)
+    nets = {}
+    for n in ("E", "G", "Gstru", "Ex", "Dreal", "Dco", "Ddist"):
+        if n == "Dco" and not big:
+            continue
+        m = init_model(TS.NET_CLASSES[n], args)
+        nets[n] = {k: v.detach().contiguous().requires_grad_(v.is_floating_point() and not k.endswith("kernel"))
+                   for k, v in m.state_dict().items()}
+    cfg = O.Cfg(image_size=R)
+    sargs = O.StepArgs(use_dco=big)
+    X = torch.rand(1, 3, R, R) * 2 - 1
+    random.seed(0)
+    dr = O.StepDraws(Z_d=torch.rand(1, 1, R // 16, R // 16) * 2 - 1, T2_d=torch.rand(1, 2048) * 2 - 1,
+                     Z_g=torch.rand(1, 1, R // 16, R // 16) * 2 - 1, T2_g=torch.rand(1, 2048) * 2 - 1)
+    if big:
+        dr.boxes_d_fake, dr.boxes_d_real = O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 8)
+        dr.boxes_d_ref, dr.boxes_g_fake, dr.boxes_g_ref = O.draw_boxes(R, R, 32), O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 32)
+    t0 = time.perf_counter()
+    d_names = [n for n in ("Dreal", "Dco", "Ddist") if n in nets]
+    d_params = [p for n in d_names for p in nets[n].values() if p.requires_grad]
+    total, _, _ = O.d_phase(nets, cfg, sargs, X, dr)
+    torch.autograd.grad(total, d_params, allow_unused=True)
+    g_params = [p for n in ("E", "G", "Gstru") for p in nets[n].values() if p.requires_grad]
+    ex_params = [p for p in nets["Ex"].values() if p.requires_grad]
+    total, ex_loss, _, _ = O.g_phase(nets, cfg, sargs, X, dr, 1)
+    torch.autograd.grad(ex_loss, ex_params, retain_graph=True)
+    torch.autograd.grad(total, g_params, allow_unused=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 iteration (D phase + G/Ex phase, no R1, no optimiser), batch 1, %dx%d, full width, %s; %.1f s"
+                      % (R, R, "with Dco" if big else "Dco-less sub-step", dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+
+    from ideas_amd import _lib, train_step as TS
+    from ideas_amd.models import init_model
+    from ideas_amd.ddp import GradReducer
+    _lib.load()
+
+    if a.roofline == "only":
+        print(json.dumps({"roofline": roofline_probe(device, a.batch, a.roofline_launches)}))
+        return
+
+    args = TS.default_args(image_size=a.image_size, batch_size=a.batch, N=a.N,
+                           elide_second_backward=not a.literal_second_backward, num_iters=10 ** 9)
+    torch.manual_seed(0)              # identical replicas on every rank (no broadcast needed)
+    trainer = TS.build_trainer(args, "cpu", init_model)
+    for v in trainer.values():
+        if isinstance(v, torch.nn.Module):
+            v.to(device)
+    random.seed(1000 + rank)
+    torch.manual_seed(1000 + rank)
+    gx = torch.Generator().manual_seed(1234 + rank)
+    X = (torch.rand(a.batch, 3, a.image_size, a.image_size, generator=gx) * 2 - 1).to(device)
+    X = X.contiguous(memory_format=torch.channels_last)
+    reducer = GradReducer() if world > 1 else None
+
+    def step(idx):
+        return TS.train_iteration(trainer, args, X, idx, reducer=reducer)
+
+    for j in range(a.warmup):
+        step(args.d_reg_every * 1000 + j)          # first warm-up iteration exercises the R1 branch
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1, a.steps + 1):
+        losses = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_r1 = sum(1 for i in range(1, a.steps + 1) if i % args.d_reg_every == 0)
+    ips = world * a.batch * a.steps / dt
+    gflop_img = flop_per_image(not a.literal_second_backward)
+    out = {
+        "metric": "train images/sec at 256x256 (G+D+Ex step)", "value": round(ips, 3), "unit": "images/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
+                               "full-width nets, HIP kernels (BASELINE.json configs[2])" % (a.N, a.image_size, a.image_size, a.batch),
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
+                   "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)"},
+        "step_gflop_per_image": round(gflop_img, 1),
+        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+        "losses": {k: round(float(v), 4) for k, v in losses.items() if v.numel() == 1},
+    }
+    if a.roofline == "on":
+        del trainer
+        torch.cuda.empty_cache()
+        out["roofline"] = roofline_probe(device, a.batch, a.roofline_launches)
+    if a.cpu_baseline == "auto" and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

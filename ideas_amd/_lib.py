@@ -36,6 +36,7 @@ class ConvParams(C.Structure):
 _P = C.c_void_p
 _PROTOS = {
     "ideas_abi_version": (C.c_int, []),
+    "ideas_sizeof_conv_params": (C.c_int, []),
     "ideas_strerror": (C.c_char_p, [C.c_int]),
     "ideas_fused_bias_act": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_float, C.c_int, _P]),
@@ -66,8 +67,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.ideas_abi_version() != 1:
-        raise RuntimeError("libideas_hip.so ABI version mismatch")
+    if lib.ideas_abi_version() != 1 or lib.ideas_sizeof_conv_params() != C.sizeof(ConvParams):
+        raise RuntimeError("libideas_hip.so ABI mismatch (version or ideas_conv_params layout)")
     _lib = lib
     return lib
 

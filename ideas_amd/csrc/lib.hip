@@ -3,6 +3,8 @@
 
 extern "C" int ideas_abi_version(void) { return IDEAS_ABI_VERSION; }
 
+extern "C" int ideas_sizeof_conv_params(void) { return (int)sizeof(ideas_conv_params); }
+
 extern "C" const char* ideas_strerror(int code) {
     switch (code) {
         case IDEAS_OK: return "ok";

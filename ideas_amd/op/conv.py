@@ -90,8 +90,9 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
         return torch.ops.aten.reflection_pad2d_backward(gxp.contiguous(), like, [g.pad] * 4)
     launches, need_zero = plan_dgrad(gy.shape, w, g, in_hw)
     b, ci = gy.shape[0], w.shape[1]
-    alloc = torch.zeros if need_zero else torch.empty
-    gx = alloc((b, ci, in_hw[0], in_hw[1]), device=gy.device, dtype=gy.dtype, memory_format=CL)
+    gx = torch.empty((b, ci, in_hw[0], in_hw[1]), device=gy.device, dtype=gy.dtype, memory_format=CL)
+    if need_zero:
+        gx.zero_()
     for L in launches:
         launch_fwd(gx, gy, L, gain, lin, lout)
     return gx
@@ -101,7 +102,7 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
     """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy."""
     gy, x = _nhwc(gy), _nhwc(x)
     L = plan_wgrad(x.shape, gy.shape, g)
-    gw = torch.zeros(tuple(w_shape), device=x.device, dtype=torch.float32, memory_format=CL)
+    gw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32, memory_format=CL).zero_()
     launch_wgrad(gw, gy, x, L, gain, lin, lout)
     return gw
 

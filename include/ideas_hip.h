@@ -42,6 +42,7 @@ enum {
 };
 
 int ideas_abi_version(void);
+int ideas_sizeof_conv_params(void);   /* lets a binding check its mirror of ideas_conv_params */
 const char* ideas_strerror(int code);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,0 +1,143 @@
+"""CPU: host-side logic of the product (no kernels): state-dict/init parity with the reference, the message
+codec, patchify, the C ABI surface, and the product's train_iteration() driven with oracle-backed networks
+against the step vectors captured from the reference's own train()."""
+import argparse
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, Golden, rel_err
+import oracle.torch_ref as O
+
+
+def test_init_matches_reference_seeded_init():
+    from ideas_amd.models import init_model
+    from ideas_amd.train_step import NET_CLASSES
+    gold = json.load(open(os.path.join(GOLDEN, "init_checksums.json")))
+    a = argparse.Namespace(channel=32, structure_channel=8, texture_channel=2048, N=1, image_size=256,
+                           channel_multiplier=1, blur_kernel=(1, 3, 3, 1))
+    for tag, cls in NET_CLASSES.items():
+        torch.manual_seed(1234)
+        net = init_model(cls, a)
+        sd = net.state_dict()
+        g = gold[tag]
+        assert [[k, list(v.shape)] for k, v in sd.items()] == g["keys"], tag       # key names, order, shapes
+        assert [k for k, _ in net.named_parameters()] == g["param_keys"], tag
+        assert sum(p.numel() for p in net.parameters()) == g["n_params"], tag
+        for k, v in g["sums"].items():
+            assert abs(float(sd[k].double().sum()) - v) < 1e-9, (tag, k)
+        assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - g["total_abs"]) < 1e-6 * g["total_abs"]
+
+
+def test_codec_and_patchify_product(ops_golden):
+    from ideas_amd.utils import message_to_tensor, patchify_image, tensor_to_message
+    g = ops_golden
+    for c in g.json("meta")["codec"]:
+        k = c["key"]
+        Z = message_to_tensor(g.t(k + ".M"), c["sigma"], c["delta"], jitter=g.t(k + ".jitter"))
+        assert torch.equal(Z, g.t(k + ".Z"))
+        assert torch.equal(tensor_to_message(Z, c["sigma"]), g.t(k + ".M"))
+    boxes = [tuple(int(v) for v in b) for b in g.t("patch.boxes").tolist()]
+    assert torch.equal(patchify_image(g.t("patch.img"), 3, boxes=boxes), g.t("patch.out"))
+    # edge cases: all-zero / all-one messages, values outside [-1, 1] are clamped
+    for sigma in (1, 2, 3):
+        for bit in (0.0, 1.0):
+            M = torch.full((2, 6 * sigma), bit)
+            assert torch.equal(tensor_to_message(message_to_tensor(M, sigma, 0.5), sigma), M)
+    assert torch.equal(tensor_to_message(torch.tensor([[-3.0, 3.0, 0.0, -0.0]]), 1), torch.tensor([[0.0, 1.0, 1.0, 1.0]]))
+
+
+def test_draw_boxes_matches_reference_rng_order(ops_golden):
+    import random
+    from ideas_amd.utils import draw_boxes
+    g = ops_golden
+    torch.manual_seed(11)
+    random.seed(11)
+    torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))  # independent generator: no effect
+    boxes = draw_boxes(64, 64, 3)
+    assert boxes == [tuple(int(v) for v in b) for b in g.t("patch.boxes").tolist()]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads (no GPU needed) and exports exactly what include/ideas_hip.h declares."""
+    from ideas_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ideas_hip.h")).read()
+    declared = set(re.findall(r"\b(ideas_[a-z0-9_]+)\s*\(", hdr)) - {"ideas_conv_params"}
+    assert declared, "no declarations parsed"
+    assert os.path.exists(_lib.LIB_PATH), "build libideas_hip.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ideas_hip.h but not exported"
+    assert set(_lib.EXPORTS) == declared
+    assert _lib.load().ideas_abi_version() == 1
+    assert _lib.load().ideas_strerror(-2) == b"bad or inconsistent dimension"
+    assert ctypes.sizeof(_lib.ConvParams) == _lib.load().ideas_sizeof_conv_params() == 28 * 4
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    import ideas_amd.op as op
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        op.fused_leaky_relu(torch.zeros(1, 4), torch.zeros(4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        op.modulated_conv2d(torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 4, 3, 3), torch.zeros(1, 4))
+
+
+# ---------------------------------------------------------------------------------------------------
+class OracleBacked(torch.nn.Module):
+    """Product module's parameters + the oracle's functional forward: lets the product step run on CPU."""
+
+    def __init__(self, module, fn, cfg):
+        super().__init__()
+        self.m, self.fn, self.cfg = module, fn, cfg
+
+    def forward(self, *a, **k):
+        P = dict(self.m.named_parameters())
+        P.update(dict(self.m.named_buffers()))
+        return self.fn(P, self.cfg, *a, **k)
+
+
+def _oracle_trainer(trainer, args):
+    cfg = O.Cfg(channel=args.channel, structure_channel=args.structure_channel, texture_channel=args.texture_channel,
+                N=args.N, image_size=args.image_size, channel_multiplier=args.channel_multiplier)
+    out = dict(trainer)
+    for name, fn in O.NETS.items():
+        if name == "Dco" and not hasattr(trainer[name], "encoder"):
+            continue   # ZeroDco stand-in
+        out[name] = OracleBacked(trainer[name], fn, cfg)
+        if name + "_ema" in trainer:
+            out[name + "_ema"] = OracleBacked(trainer[name + "_ema"], fn, cfg)
+    return out
+
+
+@pytest.mark.parametrize("which", ["r64", "r256"])
+def test_product_step_logic_against_reference_train(which):
+    """ideas_amd.train_step.train_iteration (host logic) with oracle-backed nets == reference train() vectors."""
+    from test_nets_gpu import check_replay, replay_step
+    torch.set_num_threads(8)
+    g, meta, trainer, out, log = replay_step(which, "cpu", build_nets=_oracle_trainer)
+    check_replay(g, meta, trainer, out, log)
+
+
+def test_literal_second_backward_gives_same_ex_gradient():
+    """elide_second_backward=True takes Ex's gradient over the Ex sub-graph only; the reference's literal
+    second traversal (train.py:214-215) must give the same Ex update."""
+    from ideas_amd import train_step as TS
+    from ideas_amd.models import init_model
+    from test_nets_gpu import ZeroDco
+    res = []
+    for elide in (True, False):
+        args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=64, batch_size=1,
+                               d_reg_every=4, num_iters=10, elide_second_backward=elide)
+        torch.manual_seed(5)
+        tr = _oracle_trainer(TS.build_trainer(args, "cpu", init_model, dco_factory=ZeroDco), args)
+        torch.manual_seed(6)
+        import random
+        random.seed(6)
+        X = torch.rand(1, 3, 64, 64) * 2 - 1
+        TS.train_iteration(tr, args, X, 1)
+        res.append(torch.cat([p.detach().flatten() for p in tr["Ex"].parameters()]))
+    assert torch.allclose(res[0], res[1], rtol=0, atol=1e-7)

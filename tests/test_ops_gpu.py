@@ -1,0 +1,270 @@
+"""GPU parity: every HIP op (through the C ABI) against the golden vectors and the CPU oracle.
+
+Tolerances: elementwise bias+act is bit-exact; everything that sums is within 1e-5 * max|ref|
+forward and 1e-4 * max|ref| for gradients (the reference's own fp32 noise floor is ~3e-6).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+import oracle.torch_ref as O
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+TOL, GTOL = 1e-5, 1e-4
+
+
+def dev(t, cl=False):
+    t = t.detach().cuda()
+    if cl and t.dim() == 4:
+        t = t.contiguous(memory_format=CL)
+    return t
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import ideas_amd.op as op
+    return op
+
+
+# --------------------------------------------------------------------------------------------- bias_act
+@pytest.mark.parametrize("tag", ["flr4", "flr2"])
+@pytest.mark.parametrize("cl", [False, True])
+def test_fused_leaky_relu_golden(ops, ops_golden, tag, cl):
+    g = ops_golden
+    x = dev(g.t(f"{tag}.x"), cl).requires_grad_(True)
+    b = dev(g.t(f"{tag}.b")).requires_grad_(True)
+    y = ops.fused_leaky_relu(x, b)
+    assert torch.equal(y.cpu(), g.t(f"{tag}.y"))                      # bit-exact
+    gy = dev(g.t(f"{tag}.gy"), cl).requires_grad_(True)
+    gx, gb = torch.autograd.grad(y, (x, b), gy, create_graph=True)
+    # backward: the kernel (like the reference's CUDA kernel) does (g*alpha)*scale, the CPU composite's autograd
+    # does (g*scale)*alpha -> equal to 1 ulp, not bitwise
+    assert rel_err(gx, g.t(f"{tag}.gx")) < 2e-7
+    assert rel_err(gb, g.t(f"{tag}.gb")) < 1e-6
+    (ggy,) = torch.autograd.grad((gx * dev(g.t(f"{tag}.ggx"), cl)).sum() + (gb * dev(g.t(f"{tag}.ggb"))).sum(), gy)
+    assert rel_err(ggy, g.t(f"{tag}.ggy")) < 1e-6
+
+
+@pytest.mark.parametrize("shape,cl", [((3, 8, 5, 7), True), ((2, 64, 33, 31), True), ((2, 12, 9, 9), True),
+                                      ((4, 3, 16, 16), True), ((2, 64, 33, 32), False), ((3, 5, 7, 9), False),
+                                      ((32, 2048), False), ((5, 384, 8, 8), True), ((1, 1, 1, 1), False),
+                                      ((2, 768, 2, 2), True)])
+def test_fused_leaky_relu_random(ops, shape, cl):
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape).requires_grad_(True)
+    b = torch.randn(shape[1]).requires_grad_(True)
+    gy = torch.randn(*shape)
+    y = O.fused_leaky_relu(x, b)
+    gx, gb = torch.autograd.grad(y, (x, b), gy)
+    xd, bd = dev(x, cl).requires_grad_(True), dev(b).requires_grad_(True)
+    yd = ops.fused_leaky_relu(xd, bd)
+    gxd, gbd = torch.autograd.grad(yd, (xd, bd), dev(gy, cl))
+    assert torch.equal(yd.cpu(), y.detach())
+    assert rel_err(gxd, gx) < 2e-7
+    assert rel_err(gbd, gb) < 1e-5
+
+
+def test_fused_leaky_relu_no_bias_and_slope(ops):
+    x = torch.randn(2, 8, 4, 4)
+    y = ops.fused_leaky_relu(dev(x, True), None, 0.1, 1.5)
+    assert torch.equal(y.cpu(), F.leaky_relu(x, 0.1) * 1.5)
+
+
+def test_ops_refuse_cpu(ops):
+    with pytest.raises(RuntimeError):
+        ops.fused_leaky_relu(torch.randn(2, 4), torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        ops.upfirdn2d(torch.randn(1, 1, 4, 4), torch.ones(2, 2))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.randn(1, 4, 4, 4), torch.randn(4, 4, 1, 1))
+
+
+# --------------------------------------------------------------------------------------------- upfirdn2d
+@pytest.mark.parametrize("cl", [False, True])
+def test_upfirdn2d_golden(ops, ops_golden, cl):
+    g = ops_golden
+    k1 = O.make_kernel((1, 3, 3, 1))
+    for m in g.json("meta")["blur"]:
+        i = m["i"]
+        x = dev(g.t(f"blur{i}.x"), cl).requires_grad_(True)
+        k = dev(k1 * m["gain"])
+        y = ops.upfirdn2d(x, k, up=m["up"], down=m["down"], pad=tuple(m["pad"]))
+        ref = g.t(f"blur{i}.y")
+        assert tuple(y.shape) == tuple(ref.shape), m
+        assert rel_err(y, ref) < 1e-6, m
+        (gx,) = torch.autograd.grad(y, x, dev(g.t(f"blur{i}.gy"), cl))
+        assert rel_err(gx, g.t(f"blur{i}.gx")) < 1e-6, m
+    y = ops.upfirdn2d(dev(g.t("blurasym.x"), cl), dev(g.t("blurasym.k")), pad=(1, 1))
+    assert rel_err(y, g.t("blurasym.y")) < 1e-6
+    d = torch.eye(16)[5].view(1, 1, 4, 4)
+    assert rel_err(ops.upfirdn2d(dev(d, cl), dev(k1), pad=(2, 2)), g.t("blur.delta22")) < 1e-6
+
+
+@pytest.mark.parametrize("shape,pad,gain,cl", [((2, 8, 33, 31), (2, 2), 1, True), ((2, 8, 33, 31), (1, 1), 4, True),
+                                               ((3, 64, 65, 65), (1, 1), 4, True), ((2, 12, 63, 63), (2, 2), 1, True),
+                                               ((2, 3, 40, 70), (2, 2), 1, False), ((1, 5, 129, 17), (1, 1), 1, False),
+                                               ((2, 6, 9, 9), (2, 2), 1, True), ((2, 4, 1, 1), (2, 2), 1, True)])
+def test_upfirdn2d_random_with_double_backward(ops, shape, pad, gain, cl):
+    torch.manual_seed(sum(shape))
+    k = O.make_kernel((1, 3, 3, 1)) * gain
+    x = torch.randn(*shape, dtype=torch.float64).requires_grad_(True)
+    y = O.upfirdn2d(x, k.double(), pad=pad)
+    gy = torch.randn_like(y).requires_grad_(True)
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    ggx = torch.randn_like(gx)
+    (ggy,) = torch.autograd.grad(gx, gy, ggx)
+    xd = dev(x.float(), cl).requires_grad_(True)
+    yd = ops.upfirdn2d(xd, dev(k), pad=pad)
+    gyd = dev(gy.float(), cl).requires_grad_(True)
+    (gxd,) = torch.autograd.grad(yd, xd, gyd, create_graph=True)
+    (ggyd,) = torch.autograd.grad(gxd, gyd, dev(ggx.float(), cl))
+    assert rel_err(yd, y) < 2e-6 and rel_err(gxd, gx) < 2e-6 and rel_err(ggyd, ggy) < 2e-6
+    assert yd.is_contiguous(memory_format=CL) == cl or yd.is_contiguous()
+
+
+# --------------------------------------------------------------------------------------------- conv
+def test_conv_golden(ops, ops_golden):
+    g = ops_golden
+    for m in g.json("meta")["conv"]:
+        i = m["i"]
+        scale = 1 / math.sqrt(m["cin"] * m["k"] ** 2)
+        x = dev(g.t(f"conv{i}.x"), True).requires_grad_(True)
+        w = dev(g.t(f"conv{i}.w"), True).requires_grad_(True)
+        b = dev(g.t(f"conv{i}.b")).requires_grad_(True) if m["bias"] else None
+        y = ops.conv2d(x, w, b, stride=m["stride"], padding=m["padding"], gain=scale)
+        assert rel_err(y, g.t(f"conv{i}.y")) < TOL, m
+        grads = torch.autograd.grad(y, [x, w] + ([b] if b is not None else []), dev(g.t(f"conv{i}.gy"), True))
+        assert rel_err(grads[0], g.t(f"conv{i}.gx")) < GTOL, m
+        assert rel_err(grads[1], g.t(f"conv{i}.gw")) < GTOL, m
+        if b is not None:
+            assert rel_err(grads[2], g.t(f"conv{i}.gb")) < GTOL
+    x, w = dev(g.t("convT.x"), True).requires_grad_(True), dev(g.t("convT.w"), True).requires_grad_(True)
+    y = ops.conv_transpose2d(x, w, None, stride=2, gain=1 / math.sqrt(8))
+    assert rel_err(y, g.t("convT.y")) < TOL
+    gx, gw = torch.autograd.grad(y, (x, w), dev(g.t("convT.gy"), True))
+    assert rel_err(gx, g.t("convT.gx")) < GTOL and rel_err(gw, g.t("convT.gw")) < GTOL
+
+
+CONV_CASES = [
+    # B, Cin, Cout, k, stride, pad, reflect, H, W
+    (2, 8, 16, 3, 1, 1, False, 9, 11), (3, 32, 64, 3, 1, 1, False, 17, 16), (2, 64, 128, 3, 1, 1, False, 24, 24),
+    (2, 64, 130, 3, 1, 1, False, 13, 13), (2, 128, 100, 1, 1, 0, False, 16, 16), (2, 12, 40, 3, 1, 0, False, 10, 10),
+    (2, 32, 64, 3, 2, 0, False, 33, 33), (2, 64, 64, 1, 2, 0, False, 31, 31), (2, 16, 24, 2, 1, 0, False, 2, 2),
+    (2, 32, 64, 3, 1, 1, True, 16, 16), (2, 8, 8, 3, 1, 1, True, 4, 4), (1, 256, 256, 3, 1, 1, False, 8, 8),
+    (2, 128, 3, 1, 1, 0, False, 32, 32), (2, 3, 32, 1, 1, 0, False, 20, 20), (2, 32, 1, 1, 1, 0, False, 4, 4),
+    (2, 1, 32, 1, 1, 0, False, 4, 4), (2, 512, 8, 1, 1, 0, False, 16, 16), (5, 20, 36, 3, 2, 0, False, 17, 17),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_random_vs_oracle(ops, case):
+    B, ci, co, k, s, p, refl, H, W = case
+    torch.manual_seed(sum(case[:6]) + H)
+    x = torch.randn(B, ci, H, W, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(co, ci, k, k, dtype=torch.float64).requires_grad_(True)
+    scale = 1 / math.sqrt(ci * k * k)
+    xin = F.pad(x, [p] * 4, mode="reflect") if refl else x
+    y = F.conv2d(xin, w * scale, stride=s, padding=0 if refl else p)
+    gy = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    xd = dev(x.float(), True).requires_grad_(True)
+    wd = dev(w.float(), True).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, None, stride=s, padding=p, reflect=refl, gain=scale)
+    assert tuple(yd.shape) == tuple(y.shape)
+    assert rel_err(yd, y) < TOL, ("y", case, rel_err(yd, y))
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), dev(gy.float(), True))
+    assert rel_err(gxd, gx) < GTOL, ("gx", case, rel_err(gxd, gx))
+    assert rel_err(gwd, gw) < GTOL, ("gw", case, rel_err(gwd, gw))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 1, 2, 7, 7), (2, 64, 32, 1, 2, 16, 16), (2, 32, 48, 3, 2, 9, 9), (1, 8, 8, 3, 1, 5, 5)])
+def test_conv_transpose_random_vs_oracle(ops, case):
+    B, ci, co, k, s, H, W = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(ci, co, k, k, dtype=torch.float64).requires_grad_(True)
+    scale = 1 / math.sqrt(ci * k * k)
+    y = F.conv_transpose2d(x, w * scale, stride=s)
+    gy = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    xd, wd = dev(x.float(), True).requires_grad_(True), dev(w.float(), True).requires_grad_(True)
+    yd = ops.conv_transpose2d(xd, wd, None, stride=s, gain=scale)
+    assert rel_err(yd, y) < TOL
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), dev(gy.float(), True))
+    assert rel_err(gxd, gx) < GTOL and rel_err(gwd, gw) < GTOL
+
+
+@pytest.mark.parametrize("case", [(2, 8, 16, 3, 1, 1, 8), (2, 16, 16, 3, 2, 0, 9), (2, 3, 8, 1, 1, 0, 6), (2, 8, 8, 1, 2, 0, 7)])
+def test_conv_double_backward_r1(ops, case):
+    """R1-style second order: d/dw of |d(sum y)/dx|^2 through conv -> lrelu -> conv (utils.py:112-118)."""
+    B, ci, co, k, s, p, H = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, ci, H, H, dtype=torch.float64)
+    w1 = torch.randn(co, ci, k, k, dtype=torch.float64)
+    w2 = torch.randn(4, co, 1, 1, dtype=torch.float64)
+    b1 = torch.randn(co, dtype=torch.float64) * 0.1
+
+    def run(conv, act, x, w1, b1, w2):
+        x = x.clone().requires_grad_(True)
+        w1, b1, w2 = (t.clone().requires_grad_(True) for t in (w1, b1, w2))
+        h = act(conv(x, w1, s, p), b1)
+        out = conv(h, w2, 1, 0)
+        (gx,) = torch.autograd.grad(out.sum(), x, create_graph=True)
+        r1 = gx.pow(2).reshape(B, -1).sum(1).mean()
+        gw1, gb1, gw2 = torch.autograd.grad(r1, (w1, b1, w2))
+        return r1, gw1, gb1, gw2
+
+    ref = run(lambda a, w, st, pd: F.conv2d(a, w, stride=st, padding=pd), O.fused_leaky_relu, x, w1, b1, w2)
+    got = run(lambda a, w, st, pd: ops.conv2d(a, w, None, stride=st, padding=pd), ops.fused_leaky_relu,
+              dev(x.float(), True), dev(w1.float(), True), dev(b1.float()), dev(w2.float(), True))
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 5e-4, (case, rel_err(a, b))
+
+
+# --------------------------------------------------------------------------------------------- modulated conv
+def _mod_ref(x, st, w, mw, mb, up):
+    return O.modulated_conv2d(x, st, w, mw, mb, upsample=up)
+
+
+def test_modconv_golden(ops, ops_golden):
+    from ideas_amd.model import ModulatedConv2d
+    g = ops_golden
+    for m in g.json("meta")["mod"]:
+        i = m["i"]
+        mod = ModulatedConv2d(m["cin"], m["cout"], 3, 24, upsample=m["up"]).cuda()
+        mod.weight.data.copy_(g.t(f"mod{i}.w"))
+        mod.modulation.weight.data.copy_(g.t(f"mod{i}.mw"))
+        mod.modulation.bias.data.copy_(g.t(f"mod{i}.mb"))
+        x = dev(g.t(f"mod{i}.x"), True).requires_grad_(True)
+        st = dev(g.t(f"mod{i}.style")).requires_grad_(True)
+        y = mod(x, st)
+        assert rel_err(y, g.t(f"mod{i}.y")) < TOL, (m, rel_err(y, g.t(f"mod{i}.y")))
+        grads = torch.autograd.grad(y, (x, st, mod.weight, mod.modulation.weight, mod.modulation.bias),
+                                    dev(g.t(f"mod{i}.gy"), True))
+        for got, k in zip(grads, ("gx", "gstyle", "gw", "gmw", "gmb")):
+            assert rel_err(got, g.t(f"mod{i}.{k}")) < GTOL, (m, k, rel_err(got, g.t(f"mod{i}.{k}")))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 128, False, 16), (2, 128, 64, True, 16), (3, 8, 128, False, 16), (2, 96, 96, True, 9)])
+def test_modconv_random_vs_oracle(ops, case):
+    from ideas_amd.model import ModulatedConv2d
+    B, ci, co, up, H = case
+    torch.manual_seed(sum(case[:3]) + H)
+    mod = ModulatedConv2d(ci, co, 3, 64, upsample=up)
+    x = torch.randn(B, ci, H, H, dtype=torch.float64).requires_grad_(True)
+    st = torch.randn(B, 64, dtype=torch.float64).requires_grad_(True)
+    P = [p.detach().double().requires_grad_(True) for p in (mod.weight, mod.modulation.weight, mod.modulation.bias)]
+    y = _mod_ref(x, st, *P, up)
+    gy = torch.randn_like(y)
+    ref = torch.autograd.grad(y, [x, st] + P, gy)
+    mod = mod.cuda()
+    xd, sd = dev(x.float(), True).requires_grad_(True), dev(st.float()).requires_grad_(True)
+    yd = mod(xd, sd)
+    assert rel_err(yd, y) < TOL, rel_err(yd, y)
+    got = torch.autograd.grad(yd, (xd, sd, mod.weight, mod.modulation.weight, mod.modulation.bias), dev(gy.float(), True))
+    for a, b, n in zip(got, ref, ("gx", "gstyle", "gw", "gmw", "gmb")):
+        assert rel_err(a, b) < GTOL, (n, case, rel_err(a, b))
