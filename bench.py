@@ -87,17 +87,13 @@ def roofline_probe(device, batch: int, launches: int):
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
-def cpu_baseline():
-    """The oracle's step (oracle/torch_ref.py, the CPU restatement pinned to the reference) on the host cores.
-    Bounded sample: ONE full-width iteration without the R1 branch at batch 1 — 256x256 with Dco when the host has
-    >= 32 hardware threads, else the 64x64 Dco-less sub-step (BASELINE.json configs[0])."""
+def _cpu_baseline_worker(R: int, threads: int):
+    """Runs in a child process: one oracle iteration (D phase + G/Ex phase with backward) at batch 1."""
     import oracle.torch_ref as O
     from ideas_amd.models import init_model
     from ideas_amd import train_step as TS
-    cores = os.cpu_count() or 1
-    big = cores >= 32
-    R = 256 if big else 64
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
+    big = R >= 256
     args = TS.default_args(image_size=R, use_dco=big)
     torch.manual_seed(0)
     nets = {}
@@ -111,14 +107,14 @@ def cpu_baseline():
     sargs = O.StepArgs(use_dco=big)
     X = torch.rand(1, 3, R, R) * 2 - 1
     random.seed(0)
-    dr = O.StepDraws(Z_d=torch.rand(1, 1, R // 16, R // 16) * 2 - 1, T2_d=torch.rand(1, 2048) * 2 - 1,
-                     Z_g=torch.rand(1, 1, R // 16, R // 16) * 2 - 1, T2_g=torch.rand(1, 2048) * 2 - 1)
+    s = R // 16
+    dr = O.StepDraws(Z_d=torch.rand(1, 1, s, s) * 2 - 1, T2_d=torch.rand(1, 2048) * 2 - 1,
+                     Z_g=torch.rand(1, 1, s, s) * 2 - 1, T2_g=torch.rand(1, 2048) * 2 - 1)
     if big:
         dr.boxes_d_fake, dr.boxes_d_real = O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 8)
         dr.boxes_d_ref, dr.boxes_g_fake, dr.boxes_g_ref = O.draw_boxes(R, R, 32), O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 32)
     t0 = time.perf_counter()
-    d_names = [n for n in ("Dreal", "Dco", "Ddist") if n in nets]
-    d_params = [p for n in d_names for p in nets[n].values() if p.requires_grad]
+    d_params = [p for n in ("Dreal", "Dco", "Ddist") if n in nets for p in nets[n].values() if p.requires_grad]
     total, _, _ = O.d_phase(nets, cfg, sargs, X, dr)
     torch.autograd.grad(total, d_params, allow_unused=True)
     g_params = [p for n in ("E", "G", "Gstru") for p in nets[n].values() if p.requires_grad]
@@ -126,13 +122,35 @@ def cpu_baseline():
     total, ex_loss, _, _ = O.g_phase(nets, cfg, sargs, X, dr, 1)
     torch.autograd.grad(ex_loss, ex_params, retain_graph=True)
     torch.autograd.grad(total, g_params, allow_unused=True)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 iteration (D phase + G/Ex phase, no R1, no optimiser), batch 1, %dx%d, full width, %s; %.1f s"
-                      % (R, R, "with Dco" if big else "Dco-less sub-step", dt)}
+    print(json.dumps({"seconds": time.perf_counter() - t0, "threads": torch.get_num_threads()}))
+
+
+def cpu_baseline():
+    """The oracle's step (oracle/torch_ref.py, the CPU restatement pinned to the reference) on the host cores.
+    Bounded sample: ONE full-width iteration (D phase + G/Ex phase, forward and backward, no R1, no optimiser) at
+    batch 1 — 256x256 with Dco; if that does not finish in 150 s, the 64x64 Dco-less sub-step (BASELINE.json
+    configs[0]).  Runs in a child process (thread count = min(host threads, 64)) so a slow host cannot hang the bench."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 64)
+    for R, limit in ((256, 150), (64, 120)):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(R), str(threads)],
+                               capture_output=True, text=True, timeout=limit, cwd=ROOT)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and line:
+                d = json.loads(line[-1])
+                return {"value": round(1.0 / d["seconds"], 5), "unit": "images/sec", "cores": d["threads"], "kind": "port",
+                        "sample": "1 iteration (D phase + G/Ex phase fwd+bwd, no R1, no optimiser), batch 1, %dx%d, full "
+                                  "width, %s; %.1f s" % (R, R, "with Dco" if R >= 256 else "Dco-less sub-step", d["seconds"])}
+        except subprocess.TimeoutExpired:
+            continue
+    return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "timed out"}
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
+        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+        return
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

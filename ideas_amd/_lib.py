@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libideas_hip.so")
+LIB_PATH = os.environ.get("IDEAS_HIP_LIB", os.path.join(_HERE, "libideas_hip.so"))  # override only for A/B kernel experiments
 
 NCHW, NHWC = 0, 1
 F32 = 0
@@ -47,6 +47,7 @@ _PROTOS = {
     "ideas_conv_wgrad_direct": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_demod": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ideas_pixel_dot": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
+    "ideas_act_bwd_dot": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
 }
 EXPORTS = tuple(_PROTOS)
 

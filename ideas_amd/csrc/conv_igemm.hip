@@ -24,6 +24,7 @@
 // so ids are remapped to give each XCD (= each private L2) one contiguous band of M tiles with all its N
 // tiles; 3x3 halos and the N-tile re-reads of the same activations then hit that XCD's L2.
 #include "common.hpp"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,11 +40,16 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 }
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+// component-wise select: a ternary on the float4 aggregates becomes a select between two ADDRESSES, which forces
+// the staging registers into scratch memory (seen in the ISA as scratch_store + vmcnt(0) after every load)
+__device__ __forceinline__ float4 keep4(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
 
 // =====================================================================================================
 // forward family
 // =====================================================================================================
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                             const float* __restrict__ wmat,
                                                             const float* __restrict__ in_scale,
@@ -110,7 +116,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
         k_tx = tap - k_ty * p.TX;
     }
 
-    float4 ra[A_PER], rb[B_PER];
+    float4 ra[A_PER], rs[A_PER], rb[B_PER];
+    bool oka[A_PER], okb[B_PER];
+    // gload only ISSUES loads (from a clamped, always-valid address: no exec-mask branches) and remembers the
+    // predicate; scaling and zero-masking happen in lstore, i.e. after the MFMAs of the current step, so the loads
+    // of step t+1 stay in flight under the matrix work of step t.
     auto gload = [&](int kt) {
         const bool kvalid = k_ty < p.TY;
 #pragma unroll
@@ -118,24 +128,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
             int iy = a_iyb[j] + k_ty * p.dy;
             int ix = a_ixb[j] + k_tx * p.dx;
             bool ok = a_ok[j] && kvalid;
-            if (p.reflect) {
+            if (REFLECT) {
                 iy = reflect_coord(iy, p.IH);
                 ix = reflect_coord(ix, p.IW);
             } else {
                 ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
             }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(x + a_base[j] + ((int64_t)iy * p.IW + ix) * p.Cin + k_ci);
-                if (in_scale) v = mul4(v, *reinterpret_cast<const float4*>(in_scale + (int64_t)a_b[j] * p.Cin + k_ci));
-            }
-            ra[j] = v;
+            const int64_t off = ok ? a_base[j] + ((int64_t)iy * p.IW + ix) * p.Cin + k_ci : 0;
+            ra[j] = *reinterpret_cast<const float4*>(x + off);
+            if (SCALE) rs[j] = *reinterpret_cast<const float4*>(in_scale + (int64_t)a_b[j] * p.Cin + k_ci);
+            oka[j] = ok;
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_ok[j] && kvalid) v = *reinterpret_cast<const float4*>(b_ptr[j] + (int64_t)kt * BK);
-            rb[j] = v;
+            const bool ok = b_ok[j] && kvalid;
+            rb[j] = *reinterpret_cast<const float4*>(ok ? b_ptr[j] + (int64_t)kt * BK : wmat);
+            okb[j] = ok;
         }
         // advance the walker by one K-step
         k_ci += BK;
@@ -148,12 +156,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
             const int r = (t >> 2) + 64 * j;
-            if (r < BM) *reinterpret_cast<float4*>(As + ((buf * BM + r) * LDK + kq * 4)) = ra[j];
+            float4 v = ra[j];
+            if (SCALE) v = mul4(v, rs[j]);
+            v = keep4(oka[j], v);
+            if (r < BM) *reinterpret_cast<float4*>(As + ((buf * BM + r) * LDK + kq * 4)) = v;
         }
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
             const int r = (t >> 2) + 64 * j;
-            if (r < BN) *reinterpret_cast<float4*>(Bs + ((buf * BN + r) * LDK + kq * 4)) = rb[j];
+            const float4 v = keep4(okb[j], rb[j]);
+            if (r < BN) *reinterpret_cast<float4*>(Bs + ((buf * BN + r) * LDK + kq * 4)) = v;
         }
     };
 
@@ -203,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the consumption of the prefetched tile behind the MFMAs
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
 //   MFMA operands are read with conflict-free ds_read_b32.  The pixel axis is split over blockIdx.y
 //   (split-K); partial tiles are combined with f32 atomics into the caller-zeroed gw.
 // =====================================================================================================
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ in_scale,
@@ -309,60 +322,82 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(float* __restrict__ 
         x_tx[j] = tap - x_ty[j] * p.TX;
     }
 
-    float4 rg[G_PER], rx[X_PER];
-    auto gload = [&](int64_t pstep) {
+    // pixel walkers: (b, oy, ox) of the pixel row each load slot handles, advanced by BK per step with 32-bit
+    // adds/compares (no integer division in the loop); `left` = pixels remaining before pend for that slot.
+    struct Walk { int b, oy, ox, left; };
+    auto walk_init = [&](int pr) {
+        Walk wk;
+        const int64_t pp = pbeg + pr;
+        wk.left = (int)(pend - pp);
+        const int64_t q = pp / p.OW;
+        wk.ox = (int)(pp - q * p.OW);
+        wk.b = (int)(q / p.OH);
+        wk.oy = (int)(q - (int64_t)wk.b * p.OH);
+        return wk;
+    };
+    auto walk_step = [&](Walk& wk) {
+        wk.left -= BK;
+        wk.ox += BK;
+        while (wk.ox >= p.OW) {
+            wk.ox -= p.OW;
+            if (++wk.oy == p.OH) { wk.oy = 0; ++wk.b; }
+        }
+    };
+    Walk gwk[G_PER], xwk[X_PER];
+#pragma unroll
+    for (int j = 0; j < G_PER; ++j) gwk[j] = walk_init(g_pr[j]);
+#pragma unroll
+    for (int j = 0; j < X_PER; ++j) xwk[j] = walk_init(x_pr[j]);
+
+    float4 rg[G_PER], rgs[G_PER], rx[X_PER], rxs[X_PER];
+    bool okg[G_PER], okx[X_PER];
+    auto gload = [&]() {   // issue only; scale + mask in lstore (after the MFMAs)
 #pragma unroll
         for (int j = 0; j < G_PER; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int64_t pp = pstep + g_pr[j];
-            if (g_ok[j] && pp < pend) {
-                const int ox = (int)(pp % p.OW);
-                const int64_t q = pp / p.OW;
-                const int oy = (int)(q % p.OH);
-                const int b = (int)(q / p.OH);
-                v = *reinterpret_cast<const float4*>(
-                    gy + (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + g_o[j]);
-                if (out_scale) v = mul4(v, *reinterpret_cast<const float4*>(out_scale + (int64_t)b * p.Cout + g_o[j]));
-            }
-            rg[j] = v;
+            const Walk wk = gwk[j];
+            const bool ok = g_ok[j] && wk.left > 0;
+            const int64_t off = ok ? (((int64_t)wk.b * p.YH + (wk.oy * p.osy + p.ooy)) * p.YW + (wk.ox * p.osx + p.oox)) * p.Cout + g_o[j] : 0;
+            rg[j] = *reinterpret_cast<const float4*>(gy + off);
+            if (SCALE) rgs[j] = *reinterpret_cast<const float4*>(out_scale + (ok ? (int64_t)wk.b * p.Cout + g_o[j] : 0));
+            okg[j] = ok;
+            walk_step(gwk[j]);
         }
 #pragma unroll
         for (int j = 0; j < X_PER; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int64_t pp = pstep + x_pr[j];
-            if (x_ok[j] && pp < pend) {
-                const int ox = (int)(pp % p.OW);
-                const int64_t q = pp / p.OW;
-                const int oy = (int)(q % p.OH);
-                const int b = (int)(q / p.OH);
-                int iy = oy * p.sy + x_ty[j] * p.dy + p.offy;
-                int ix = ox * p.sx + x_tx[j] * p.dx + p.offx;
-                bool ok = true;
-                if (p.reflect) {
-                    iy = reflect_coord(iy, p.IH);
-                    ix = reflect_coord(ix, p.IW);
-                } else {
-                    ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-                }
-                if (ok) {
-                    v = *reinterpret_cast<const float4*>(x + (((int64_t)b * p.IH + iy) * p.IW + ix) * p.Cin + x_ci[j]);
-                    if (in_scale) v = mul4(v, *reinterpret_cast<const float4*>(in_scale + (int64_t)b * p.Cin + x_ci[j]));
-                }
+            const Walk wk = xwk[j];
+            int iy = wk.oy * p.sy + x_ty[j] * p.dy + p.offy;
+            int ix = wk.ox * p.sx + x_tx[j] * p.dx + p.offx;
+            bool ok = x_ok[j] && wk.left > 0;
+            if (REFLECT) {
+                iy = reflect_coord(iy, p.IH);
+                ix = reflect_coord(ix, p.IW);
+            } else {
+                ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
             }
-            rx[j] = v;
+            const int64_t off = ok ? (((int64_t)wk.b * p.IH + iy) * p.IW + ix) * p.Cin + x_ci[j] : 0;
+            rx[j] = *reinterpret_cast<const float4*>(x + off);
+            if (SCALE) rxs[j] = *reinterpret_cast<const float4*>(in_scale + (ok ? (int64_t)wk.b * p.Cin + x_ci[j] : 0));
+            okx[j] = ok;
+            walk_step(xwk[j]);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < G_PER; ++j) {
             const int idx = t + 256 * j;
+            float4 v = rg[j];
+            if (SCALE) v = mul4(v, rgs[j]);
+            v = keep4(okg[j], v);
             if (idx < BK * BM / 4)
-                *reinterpret_cast<float4*>(Gs + ((buf * BK + g_pr[j]) * LDM + (idx % (BM / 4)) * 4)) = rg[j];
+                *reinterpret_cast<float4*>(Gs + ((buf * BK + g_pr[j]) * LDM + (idx % (BM / 4)) * 4)) = v;
         }
 #pragma unroll
         for (int j = 0; j < X_PER; ++j) {
             const int idx = t + 256 * j;
-            if (idx < BK * BN / 4) *reinterpret_cast<float4*>(Xs + ((buf * BK + x_pr[j]) * LDN + x_col[j])) = rx[j];
+            float4 v = rx[j];
+            if (SCALE) v = mul4(v, rxs[j]);
+            v = keep4(okx[j], v);
+            if (idx < BK * BN / 4) *reinterpret_cast<float4*>(Xs + ((buf * BK + x_pr[j]) * LDN + x_col[j])) = v;
         }
     };
 
@@ -378,12 +413,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(float* __restrict__ 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int64_t nsteps = (pend - pbeg + BK - 1) / BK;
-    gload(pbeg);
+    gload();
     lstore(0);
     __syncthreads();
     for (int64_t s = 0; s < nsteps; ++s) {
         const int buf = (int)(s & 1);
-        if (s + 1 < nsteps) gload(pbeg + (s + 1) * BK);
+        if (s + 1 < nsteps) gload();
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float av[MT], bv[NT];
@@ -397,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(float* __restrict__ 
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -424,6 +460,55 @@ int check_conv(const ideas_conv_params* p) {
     return IDEAS_OK;
 }
 
+template <int WM, int WN, int MT, int NT>
+int launch_fwd_cfg(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
+                   const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    const int64_t tm = ideas_cdiv(M, BM_);
+    const int tn = (int)ideas_cdiv(p->Cout, BN_);
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
+                           dim3((unsigned)(tm * tn)), dim3(256), 0, stream, (float*)y, (const float*)x,
+                           (const float*)wmat, in_scale, out_scale, bias, (const float*)resid, *p, tn);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                     const ideas_conv_params* p, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    const int64_t P = (int64_t)p->B * p->OH * p->OW;
+    const int Ktot = p->TY * p->TX * p->Cin;
+    const int tm = (int)ideas_cdiv(p->Cout, BM_);
+    const int tn = (int)ideas_cdiv(Ktot, BN_);
+    const int64_t tiles = (int64_t)tm * tn;
+    int64_t splits = ideas_cdiv(1024, tiles);
+    const int64_t max_splits = ideas_cdiv(P, 8 * BK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const int64_t per = ideas_cdiv(ideas_cdiv(P, splits), BK) * BK;
+    splits = ideas_cdiv(P, per);
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
+                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const float*)gy,
+                           (const float*)x, in_scale, out_scale, *p, tn, per);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool sc = in_scale && out_scale;
+    if (sc) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
 }  // namespace
 
 extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
@@ -436,22 +521,9 @@ extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const 
     if (p->Cin % 4) return IDEAS_E_ALIGN;
     if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
     hipStream_t stream = (hipStream_t)stream_;
-    const int64_t M = (int64_t)p->B * p->OH * p->OW;
-#define LAUNCH_FWD(WM, WN, MT, NT)                                                                               \
-    do {                                                                                                         \
-        constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;                                                    \
-        const int64_t tm = ideas_cdiv(M, BM_);                                                                   \
-        const int tn = (int)ideas_cdiv(p->Cout, BN_);                                                            \
-        if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;                                                        \
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT>), dim3((unsigned)(tm * tn)), dim3(256), 0, stream, \
-                           (float*)y, (const float*)x, (const float*)wmat, in_scale, out_scale, bias,            \
-                           (const float*)resid, *p, tn);                                                         \
-    } while (0)
-    if (p->Cout > 64) LAUNCH_FWD(2, 2, 2, 2);        // 128 x 128
-    else if (p->Cout > 32) LAUNCH_FWD(2, 2, 2, 1);   // 128 x 64
-    else LAUNCH_FWD(4, 1, 1, 1);                     // 128 x 32
-#undef LAUNCH_FWD
-    return ideas_launch_status();
+    if (p->Cout > 64) return launch_fwd_cfg<2, 2, 2, 2>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);  // 128x128
+    if (p->Cout > 32) return launch_fwd_cfg<2, 2, 2, 1>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);  // 128x64
+    return launch_fwd_cfg<4, 1, 1, 1>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);                    // 128x32
 }
 
 extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
@@ -461,31 +533,13 @@ extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const 
     int rc = check_conv(p);
     if (rc) return rc;
     if (p->Cin % 4 || p->Cout % 4) return IDEAS_E_ALIGN;
+    if ((in_scale == nullptr) != (out_scale == nullptr)) return IDEAS_E_UNSUPPORTED;  // both or neither
     if (!ideas_aligned16(x) || !ideas_aligned16(gy) || (in_scale && !ideas_aligned16(in_scale)) ||
         (out_scale && !ideas_aligned16(out_scale)))
         return IDEAS_E_ALIGN;
+    if ((int64_t)p->B * p->OH * p->OW >= 0x7fffffffLL) return IDEAS_E_SHAPE;
     hipStream_t stream = (hipStream_t)stream_;
-    const int64_t P = (int64_t)p->B * p->OH * p->OW;
-    const int Ktot = p->TY * p->TX * p->Cin;
-#define LAUNCH_WG(WM, WN, MT, NT)                                                                                 \
-    do {                                                                                                          \
-        constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;                                                     \
-        const int tm = (int)ideas_cdiv(p->Cout, BM_);                                                             \
-        const int tn = (int)ideas_cdiv(Ktot, BN_);                                                                \
-        const int64_t tiles = (int64_t)tm * tn;                                                                   \
-        int64_t splits = ideas_cdiv(1024, tiles);                                                                 \
-        const int64_t max_splits = ideas_cdiv(P, 8 * BK);                                                         \
-        if (splits > max_splits) splits = max_splits;                                                             \
-        if (splits < 1) splits = 1;                                                                               \
-        if (splits > 65535) splits = 65535;                                                                       \
-        int64_t per = ideas_cdiv(ideas_cdiv(P, splits), BK) * BK;                                                 \
-        splits = ideas_cdiv(P, per);                                                                              \
-        hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), \
-                           0, stream, gw, (const float*)gy, (const float*)x, in_scale, out_scale, *p, tn, per);   \
-    } while (0)
-    if (p->Cout > 64) LAUNCH_WG(2, 2, 2, 2);         // 128 (o) x 128 (k)
-    else if (p->Cout > 32) LAUNCH_WG(2, 2, 1, 2);    // 64 x 128
-    else LAUNCH_WG(1, 4, 1, 1);                      // 32 x 128
-#undef LAUNCH_WG
-    return ideas_launch_status();
+    if (p->Cout > 64) return launch_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);  // 128 (o) x 128 (k)
+    if (p->Cout > 32) return launch_wgrad_cfg<2, 2, 1, 2>(gw, gy, x, in_scale, out_scale, p, stream);  // 64 x 128
+    return launch_wgrad_cfg<1, 4, 1, 1>(gw, gy, x, in_scale, out_scale, p, stream);                    // 32 x 128
 }

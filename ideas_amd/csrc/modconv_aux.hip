@@ -64,6 +64,65 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out,
     for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(int64_t)b * C + c], s_acc[c]);
 }
 
+// Backward prologue of a fused (modulated conv + bias + leaky-ReLU): one pass over (gy, out) that produces
+//   g_pre = (out > 0 ? gy : gy*alpha) * act_gain        (the gradient w.r.t. the pre-activation)
+//   bgrad[c]   += sum_{b,p} g_pre
+//   dot[b,c]   += sum_p g_pre * pre,   pre = inverse_act(out) - bias[c]   (= demodulated conv output)
+// so the pre-activation tensor never has to be kept for the backward (d(demod) = dot / demod).
+__global__ __launch_bounds__(256) void act_bwd_dot_kernel(float* __restrict__ gpre, float* __restrict__ bgrad,
+                                                          float* __restrict__ dot, const float* __restrict__ gy,
+                                                          const float* __restrict__ out, const float* __restrict__ bias,
+                                                          int64_t P, int C, int64_t pix_per_block, float alpha,
+                                                          float act_gain) {
+    extern __shared__ float s_acc[];   // [2][C]: dot partials, bias-grad partials
+    const int b = blockIdx.y;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) s_acc[c] = 0.f;
+    __syncthreads();
+    const int64_t base = (int64_t)b * P * C;
+    const int C4 = C >> 2;
+    const float inv_gain = 1.0f / act_gain, inv_alpha = 1.0f / alpha;
+    auto rows = [&](int c4, int pr, int R) {
+        float4 accd = make_float4(0.f, 0.f, 0.f, 0.f), accb = accd;
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t pp = p0 + pr; pp < p1; pp += R) {
+            const int64_t off = base + pp * C + c4 * 4;
+            const float4 g = *reinterpret_cast<const float4*>(gy + off);
+            const float4 o = *reinterpret_cast<const float4*>(out + off);
+            float4 gp;
+#define ONE(f)                                                                    \
+    {                                                                             \
+        const float gsel = (o.f > 0.f) ? g.f : g.f * alpha;                       \
+        gp.f = gsel * act_gain;                                                   \
+        const float t = o.f * inv_gain;                                           \
+        const float pre = ((t > 0.f) ? t : t * inv_alpha) - bv.f;                 \
+        accd.f = fmaf(gp.f, pre, accd.f);                                         \
+        accb.f += gp.f;                                                           \
+    }
+            ONE(x) ONE(y) ONE(z) ONE(w)
+#undef ONE
+            *reinterpret_cast<float4*>(gpre + off) = gp;
+        }
+        atomicAdd(&s_acc[c4 * 4 + 0], accd.x); atomicAdd(&s_acc[c4 * 4 + 1], accd.y);
+        atomicAdd(&s_acc[c4 * 4 + 2], accd.z); atomicAdd(&s_acc[c4 * 4 + 3], accd.w);
+        atomicAdd(&s_acc[C + c4 * 4 + 0], accb.x); atomicAdd(&s_acc[C + c4 * 4 + 1], accb.y);
+        atomicAdd(&s_acc[C + c4 * 4 + 2], accb.z); atomicAdd(&s_acc[C + c4 * 4 + 3], accb.w);
+    };
+    if (C4 <= 256) {
+        const int R = 256 / C4;
+        const int c4 = (int)threadIdx.x % C4, pr = (int)threadIdx.x / C4;
+        if (pr < R) rows(c4, pr, R);
+    } else {
+        for (int c4 = threadIdx.x; c4 < C4; c4 += 256) rows(c4, 0, 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        atomicAdd(&dot[(int64_t)b * C + c], s_acc[c]);
+        atomicAdd(&bgrad[c], s_acc[C + c]);
+    }
+}
+
 }  // namespace
 
 extern "C" int ideas_demod(float* d, const float* s, const float* wsq, int B, int Cin, int Cout, float eps,
@@ -90,5 +149,26 @@ extern "C" int ideas_pixel_dot(float* out, const void* a, const void* g, int B, 
     chunks = ideas_cdiv(P, per);
     hipLaunchKernelGGL(pixel_dot_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), (size_t)C * sizeof(float),
                        (hipStream_t)stream, out, (const float*)a, (const float*)g, P, C, per);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out,
+                                 const float* bias, int B, int64_t P, int C, float alpha, float act_gain, int dtype,
+                                 void* stream) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!gpre || !bias_grad || !dot || !gy || !out) return IDEAS_E_NULL;
+    if (B <= 0 || P <= 0 || C <= 0 || C > 6144 || B > 65535) return IDEAS_E_SHAPE;
+    if (C & 3) return IDEAS_E_ALIGN;
+    if (!ideas_aligned16(gpre) || !ideas_aligned16(gy) || !ideas_aligned16(out) || (bias && !ideas_aligned16(bias)))
+        return IDEAS_E_ALIGN;
+    int64_t chunks = ideas_cdiv(2048, B);
+    const int64_t max_chunks = ideas_cdiv(P, 64);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    const int64_t per = ideas_cdiv(P, chunks);
+    chunks = ideas_cdiv(P, per);
+    hipLaunchKernelGGL(act_bwd_dot_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), (size_t)2 * C * sizeof(float),
+                       (hipStream_t)stream, (float*)gpre, bias_grad, dot, (const float*)gy, (const float*)out, bias, P, C,
+                       per, alpha, act_gain);
     return ideas_launch_status();
 }

@@ -95,16 +95,20 @@ __global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const 
 
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
-    bool colok[4];
+    unsigned colmask = 0;   // bit t: column ix0+t is inside the image (a bool[4] ends up in scratch memory)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) colok[t] = (ix0 + t >= 0) && (ix0 + t < p.in_w);
+    for (int t = 0; t < 4; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
 
     float4 w[4][4];
     auto load_row = [&](int iy, float4 (&dst)[4]) {
         const bool rowok = (iy >= 0) && (iy < p.in_h);
         const float4* xr = xb + ((int64_t)iy * p.in_w + ix0) * C4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) dst[t] = (rowok && colok[t]) ? xr[(int64_t)t * C4] : zero;
+        for (int t = 0; t < 4; ++t) {
+            float4 v = zero;
+            if (rowok && ((colmask >> t) & 1u)) v = xr[(int64_t)t * C4];
+            dst[t] = v;
+        }
     };
     const int iy0 = oy0 - p.pad_y0;
     load_row(iy0 + 0, w[0]);

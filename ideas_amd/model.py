@@ -17,7 +17,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from .op import FusedLeakyReLU, conv2d, fused_leaky_relu, modulated_conv2d, upfirdn2d
+from .op import FusedLeakyReLU, conv2d, conv2d_bias_act, fused_leaky_relu, modulated_conv2d, upfirdn2d
 
 CL = torch.channels_last
 
@@ -57,11 +57,14 @@ class EqualConv2d(nn.Module):
         self.padding = padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, input, reflect_pad: int = 0):
-        if reflect_pad:
-            return conv2d(input, self.weight, self.bias, stride=self.stride, padding=reflect_pad, reflect=True,
-                          gain=self.scale)
-        return conv2d(input, self.weight, self.bias, stride=self.stride, padding=self.padding, gain=self.scale)
+    def forward(self, input, reflect_pad: int = 0, act: Optional[FusedLeakyReLU] = None):
+        """``act``: the FusedLeakyReLU that follows in the ConvLayer — folded into the conv epilogue."""
+        pad, refl = (reflect_pad, True) if reflect_pad else (self.padding, False)
+        if act is not None and self.bias is None:
+            return conv2d_bias_act(input, self.weight, act.bias, stride=self.stride, padding=pad, reflect=refl,
+                                   gain=self.scale, negative_slope=act.negative_slope, scale=act.scale)
+        out = conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl, gain=self.scale)
+        return out if act is None else act(out)
 
     def __repr__(self):
         o, i, k, _ = self.weight.shape
@@ -122,11 +125,14 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, input, style):
+    def forward(self, input, style, act: Optional[FusedLeakyReLU] = None):
         s = self.modulation(style)
         fir = self.blur.kernel if self.upsample else None
+        if act is None:
+            return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
+                                    eps=self.eps)
         return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
-                                eps=self.eps)
+                                eps=self.eps, act_bias=act.bias, negative_slope=act.negative_slope, act_scale=act.scale)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -142,4 +148,4 @@ class StyledConv_without_noise(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
-        return self.activate(self.conv(input, style))
+        return self.conv(input, style, act=self.activate)   # bias + leaky-ReLU folded into the conv epilogue

@@ -98,9 +98,15 @@ class ConvLayer(nn.Sequential):
         i = 0
         while i < len(mods):
             m = mods[i]
+            refl = 0
             if isinstance(m, nn.ReflectionPad2d) and i + 1 < len(mods) and isinstance(mods[i + 1], EqualConv2d):
-                x = mods[i + 1](x, reflect_pad=m.padding[0])   # mirror padding folded into the conv gather
-                i += 2
+                refl = m.padding[0]                            # mirror padding folded into the conv gather
+                i += 1
+                m = mods[i]
+            if isinstance(m, EqualConv2d):
+                act = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], FusedLeakyReLU) else None
+                x = m(x, reflect_pad=refl, act=act)            # bias + leaky-ReLU folded into the conv epilogue
+                i += 2 if act is not None else 1
                 continue
             x = m(x)
             i += 1

@@ -68,13 +68,13 @@ def launch_wgrad(gw: torch.Tensor, gy: torch.Tensor, x: torch.Tensor, L: Launch,
 # ----------------------------------------------------------------------------------------------------
 
 def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None, act=False, act_gain=1.0,
-                 resid=None, resid_gain=1.0):
+                 resid=None, resid_gain=1.0, alpha=0.2):
     x = _nhwc(x)
     L = plan_fwd(x.shape, w, g)
     y = torch.empty((L.B, L.Cout, L.YH, L.YW), device=x.device, dtype=x.dtype, memory_format=CL)
     if resid is not None:
         resid = _nhwc(resid)
-    launch_fwd(y, x, L, gain, lin, lout, bias, resid, act=act, act_gain=act_gain, resid_gain=resid_gain)
+    launch_fwd(y, x, L, gain, lin, lout, bias, resid, act=act, alpha=alpha, act_gain=act_gain, resid_gain=resid_gain)
     return y
 
 
@@ -102,6 +102,11 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
     """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy."""
     gy, x = _nhwc(gy), _nhwc(x)
     L = plan_wgrad(x.shape, gy.shape, g)
+    if (lin is None) != (lout is None):   # the MFMA wgrad kernel takes both per-sample scales or neither
+        if lin is None:
+            lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+        else:
+            lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
     gw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32, memory_format=CL).zero_()
     launch_wgrad(gw, gy, x, L, gain, lin, lout)
     return gw
@@ -183,6 +188,41 @@ def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
+
+
+class _ConvBiasAct(Function):
+    """y = lrelu(gain * conv(x, w) + b) * act_gain with bias + activation in the conv epilogue (one pass saved).
+    Same op order as the separate fused_bias_act kernel, so results are bitwise those of conv2d -> fused_leaky_relu.
+    The backward is composed of differentiable Functions, so double backward (R1) still works."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, g: ConvGeom, gain: float, slope: float, act_gain: float):
+        x = _nhwc(x)
+        y = conv_fwd_raw(x, w, g, gain, bias=b.contiguous(), act=True, act_gain=act_gain, alpha=slope)
+        ctx.g, ctx.gain, ctx.slope, ctx.act_gain = g, gain, slope, act_gain
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_act import FusedLeakyReLUFunctionBackward
+        x, w, y = ctx.saved_tensors
+        g_pre, gb = FusedLeakyReLUFunctionBackward.apply(gy, y, ctx.slope, ctx.act_gain, True)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(g_pre, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
+        if ctx.needs_input_grad[1]:
+            gw = _ConvWgrad.apply(g_pre, x, ctx.g, ctx.gain, tuple(w.shape))
+        return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None
+
+
+def conv2d_bias_act(input: torch.Tensor, weight: torch.Tensor, act_bias: torch.Tensor, stride: int = 1, padding: int = 0,
+                    reflect: bool = False, gain: float = 1.0, negative_slope: float = 0.2,
+                    scale: float = 2 ** 0.5) -> torch.Tensor:
+    """``fused_leaky_relu(gain * conv2d(input, weight), act_bias, negative_slope, scale)`` in one kernel."""
+    _lib.require_cuda(input, weight, act_bias)
+    g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
+    return _ConvBiasAct.apply(input, weight, act_bias, g, float(gain), float(negative_slope), float(scale))
 
 
 class _ConvT(Function):

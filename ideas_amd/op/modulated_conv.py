@@ -24,6 +24,7 @@ from .. import _lib
 from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, _nhwc
 from .conv_plan import ConvGeom, convT_out_size
 from .upfirdn2d import upfirdn2d
+from .fused_act import fused_leaky_relu
 
 
 def pixel_dot(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
@@ -107,11 +108,63 @@ class _ModConv(Function):
         return (gx if need_x else None), gw, gs, gd, None, None
 
 
+def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: float, act_gain: float):
+    """(g_pre, bias_grad[C], dot[B,C]) from the incoming gradient and the saved post-activation output."""
+    gy, out = _nhwc(gy), _nhwc(out)
+    b, c, h, w = out.shape
+    gpre = torch.empty_like(out)
+    bg = torch.zeros(c, device=out.device, dtype=torch.float32)
+    dot = torch.zeros((b, c), device=out.device, dtype=torch.float32)
+    rc = _lib.load().ideas_act_bwd_dot(_lib.ptr(gpre), _lib.ptr(bg), _lib.ptr(dot), _lib.ptr(gy), _lib.ptr(out),
+                                       _lib.ptr(bias), b, h * w, c, float(alpha), float(act_gain), _lib.F32,
+                                       _lib.stream_ptr())
+    _lib.check(rc, "ideas_act_bwd_dot")
+    return gpre, bg, dot
+
+
+class _ModConvAct(Function):
+    """Same-resolution modulated conv with bias + leaky-ReLU in the epilogue (StyledConv_without_noise,
+    stylegan2/model.py:371-377).  Only the post-activation output is kept for the backward; the pre-activation
+    needed by d(demod) is recovered inside the fused backward-prologue kernel (ideas_act_bwd_dot)."""
+
+    @staticmethod
+    def forward(ctx, x, w, s, d, b, gain: float, slope: float, act_gain: float):
+        x = _nhwc(x)
+        s, d, b = s.contiguous(), d.contiguous(), b.contiguous()
+        k = w.shape[2]
+        g = ConvGeom(k, k, 1, k // 2, False)
+        y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d, bias=b, act=True, act_gain=act_gain, alpha=slope)
+        ctx.g, ctx.gain, ctx.slope, ctx.act_gain = g, gain, slope, act_gain
+        ctx.save_for_backward(x, w, s, d, b, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, s, d, b, y = ctx.saved_tensors
+        g, gain = ctx.g, ctx.gain
+        need_x, need_w, need_s, need_d, need_b = ctx.needs_input_grad[:5]
+        gpre, gb, dot = act_bwd_dot(gy, y, b, ctx.slope, ctx.act_gain)
+        gx = gw = gs = gd = None
+        if need_x or need_s:
+            gx = conv_dgrad_raw(gpre, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
+        if need_w:
+            gw = conv_wgrad_raw(gpre, x, g, tuple(w.shape), gain, lin=s, lout=d)
+        if need_s:
+            ds = pixel_dot(x, gx)
+            gs = torch.where(s != 0, ds / s, torch.zeros_like(ds))
+        if need_d:
+            gd = dot / d
+        return (gx if need_x else None), gw, gs, gd, (gb if need_b else None), None, None, None
+
+
 def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, demodulate: bool = True,
-                     upsample: bool = False, fir: Optional[torch.Tensor] = None, eps: float = 1e-8) -> torch.Tensor:
+                     upsample: bool = False, fir: Optional[torch.Tensor] = None, eps: float = 1e-8,
+                     act_bias: Optional[torch.Tensor] = None, negative_slope: float = 0.2,
+                     act_scale: float = 2 ** 0.5) -> torch.Tensor:
     """``x`` [B,Cin,H,W]; ``weight`` [1,Cout,Cin,k,k] (the reference's parameter); ``style`` [B,Cin] = the
-    already-affine-transformed modulation (stylegan2/model.py:239).  ``fir`` = the 4x4 blur (x4 gain applied
-    here) used after the stride-2 transposed conv (stylegan2/model.py:202-208, 258-261)."""
+    already-affine-transformed modulation (stylegan2/model.py:239).  ``fir`` = the 4x4 blur (
+    here) used after the stride-2 transposed conv (stylegan2/model.py:202-208, 258-261); it already carries the x4
+    upsample gain.  ``act_bias`` fuses the FusedLeakyReLU that always follows (stylegan2/model.py:374-375)."""
     _lib.require_cuda(x, weight, style)
     w = weight[0] if weight.dim() == 5 else weight
     cout, cin, k, _ = w.shape
@@ -120,10 +173,15 @@ def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
     if demodulate:
         wsq = (w * w).sum(dim=(2, 3)) * (scale * scale)
         d = _Demod.apply(style, wsq, eps)
+    fuse_act = act_bias is not None and not upsample and demodulate and cout % 4 == 0
+    if fuse_act:
+        return _ModConvAct.apply(x, w, style, d, act_bias, scale, float(negative_slope), float(act_scale))
     y = _ModConv.apply(x, w, style, d, upsample, scale)
     if upsample:
         if fir is None:
             raise RuntimeError("modulated_conv2d(upsample=True) needs the blur FIR")
         p = (fir.shape[0] - 2) - (k - 1)
         y = upfirdn2d(y, fir, pad=((p + 1) // 2 + 1, p // 2 + 1))
+    if act_bias is not None:
+        y = fused_leaky_relu(y, act_bias, negative_slope, act_scale)
     return y

@@ -143,6 +143,15 @@ int ideas_demod(float* d, const float* s, const float* wsq, int B, int Cin, int 
  * without materialising per-sample weights.  out must be ZEROED float[B*C]. */
 int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, int C, int dtype, void* stream);
 
+/* Backward prologue of a fused (modulated conv + bias + leaky-ReLU), NHWC, C % 4 == 0.  One pass over the incoming
+ * gradient gy and the saved POST-activation output `out` [B,P,C]:
+ *     gpre      = (out > 0 ? gy : gy*alpha) * act_gain
+ *     bias_grad[c] += sum_{b,p} gpre                       (ZEROED float[C])
+ *     dot[b,c]     += sum_p gpre * (inverse_act(out) - bias[c])   (ZEROED float[B*C]; = <gpre, demodulated conv output>)
+ * so neither the pre-activation tensor nor a separate bias-gradient / pixel-dot pass is needed. */
+int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out, const float* bias,
+                      int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

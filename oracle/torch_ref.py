@@ -80,7 +80,7 @@ def upfirdn2d(x: Tensor, kernel: Tensor, up: int = 1, down: int = 1,
     y = F.pad(y, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
     if p0 < 0 or p1 < 0:
         y = y[:, :, max(-p0, 0): y.shape[2] - max(-p1, 0), max(-p0, 0): y.shape[3] - max(-p1, 0)]
-    y = F.conv2d(y, torch.flip(kernel, [0, 1]).view(1, 1, kh, kw).to(y.dtype))
+    y = F.conv2d(y, torch.flip(kernel, [0, 1]).view(1, 1, kh, kw).to(y))
     y = y[:, :, ::down, ::down]
     return y.reshape(n, c, y.shape[2], y.shape[3])
 
@@ -129,7 +129,7 @@ def modulated_conv2d(x: Tensor, style: Tensor, weight: Tensor, mod_w: Tensor, mo
         y = y.view(b, cout, y.shape[2], y.shape[3])
         p = (len(blur_taps) - 2) - (k - 1)
         pad = ((p + 1) // 2 + 1, p // 2 + 1)
-        return upfirdn2d(y, make_kernel(blur_taps) * 4, pad=pad)
+        return upfirdn2d(y, (make_kernel(blur_taps) * 4).to(y), pad=pad)
     xin = x.reshape(1, b * cin, h, w_)
     y = F.conv2d(xin, wt.view(b * cout, cin, k, k), padding=k // 2, groups=b)
     return y.view(b, cout, y.shape[2], y.shape[3])
@@ -144,7 +144,7 @@ def conv_layer(P: Params, pre: str, x: Tensor, k: int, *, upsample: bool = False
                blur_taps: Sequence[float] = (1, 3, 3, 1)) -> Tensor:
     """models.py:49-134 — replays the positional indices of the Sequential."""
     i = 0
-    fir = make_kernel(blur_taps).to(x.dtype)
+    fir = make_kernel(blur_taps).to(x)
     stride, pad = 1, 0
     if downsample:
         p = (len(blur_taps) - 2) + (k - 1)
@@ -339,7 +339,7 @@ NETS = {
 def message_to_tensor(message: Tensor, sigma: int, delta: float, jitter: Optional[Tensor] = None) -> Tensor:
     """utils.py:74-83.  ``jitter`` (U[0,1), same shape as the result) makes the draw explicit."""
     step = 2 / 2 ** sigma
-    nums = torch.zeros(message.shape[0], message.shape[1] // sigma)
+    nums = torch.zeros(message.shape[0], message.shape[1] // sigma, device=message.device)
     for i in range(sigma):
         nums += message[:, i::sigma] * 2 ** (sigma - i - 1)
     z = step * (nums + 0.5) - 1
@@ -351,7 +351,7 @@ def message_to_tensor(message: Tensor, sigma: int, delta: float, jitter: Optiona
 
 def tensor_to_message(z: Tensor, sigma: int) -> Tensor:
     """utils.py:86-97."""
-    msg = torch.zeros(z.shape[0], z.shape[1] * sigma)
+    msg = torch.zeros(z.shape[0], z.shape[1] * sigma, device=z.device)
     step = 2 / 2 ** sigma
     nums = (torch.clamp(z, min=-1, max=1) + 1) / step
     for i in range(sigma):

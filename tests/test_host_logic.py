@@ -141,3 +141,18 @@ def test_literal_second_backward_gives_same_ex_gradient():
         TS.train_iteration(tr, args, X, 1)
         res.append(torch.cat([p.detach().flatten() for p in tr["Ex"].parameters()]))
     assert torch.allclose(res[0], res[1], rtol=0, atol=1e-7)
+
+
+def test_flop_table_matches_reference_hooks():
+    """recompute the per-net forward GFLOPs from the product's own layer table; must match the
+    numbers hooks measured on the reference (Appendix A) to 1 %."""
+    from ideas_amd.flops import forward_flops
+    from ideas_amd.models import init_model
+    from ideas_amd.train_step import NET_CLASSES
+    a = argparse.Namespace(channel=32, structure_channel=8, texture_channel=2048, N=1, image_size=256,
+                           channel_multiplier=1, blur_kernel=(1, 3, 3, 1))
+    ref = {"E": 16.516215808, "G": 95.992446976, "Gstru": 0.207896576, "Ex": 0.1937408, "Dreal": 53.2562688,
+           "Dco": 0.998638592, "Ddist": 0.00223648}
+    for tag, cls in NET_CLASSES.items():
+        gf = forward_flops(init_model(cls, a), 256) / 1e9
+        assert abs(gf - ref[tag]) <= 0.01 * ref[tag], (tag, gf, ref[tag])

@@ -188,3 +188,37 @@ def test_dreal_from_seed(nets_golden):
     P = {k: v.detach().contiguous() for k, v in net.state_dict().items()}
     cfg = O.Cfg(**CFG_TINY)
     _check_net(g, "Dreal", O.image_discriminator, cfg, P, r1_input=0)
+
+
+# ------------------------------------------------------------------------------------------------ C oracle
+def test_c_oracle_against_golden(ops_golden):
+    """oracle/ops_c.c (plain C, double accumulation) against the reference's vectors."""
+    import numpy as np
+    import oracle.ops_c as OC
+    g = ops_golden
+    for tag in ("flr4", "flr2"):
+        y = OC.fused_bias_act(g.t(f"{tag}.x").numpy(), g.t(f"{tag}.b").numpy(), None, 3, 0, 0.2, 2 ** 0.5)
+        assert np.array_equal(y, g.t(f"{tag}.y").numpy())
+        gx = OC.fused_bias_act(g.t(f"{tag}.gy").numpy(), None, g.t(f"{tag}.y").numpy(), 3, 1, 0.2, 2 ** 0.5)
+        assert rel_err(torch.from_numpy(gx), g.t(f"{tag}.gx")) < 2e-7
+    k1 = O.make_kernel((1, 3, 3, 1)).numpy()
+    for m in g.json("meta")["blur"]:
+        i = m["i"]
+        y = OC.upfirdn2d(g.t(f"blur{i}.x").numpy(), k1 * m["gain"], m["up"], m["down"], tuple(m["pad"]))
+        assert rel_err(torch.from_numpy(y), g.t(f"blur{i}.y")) < 1e-6, m
+    y = OC.upfirdn2d(g.t("blurasym.x").numpy(), g.t("blurasym.k").numpy(), pad=(1, 1))
+    assert rel_err(torch.from_numpy(y), g.t("blurasym.y")) < 1e-6
+    for m in g.json("meta")["conv"]:
+        i = m["i"]
+        b = g.t(f"conv{i}.b").numpy() if m["bias"] else None
+        y = OC.conv2d(g.t(f"conv{i}.x").numpy(), g.t(f"conv{i}.w").numpy(), b, m["stride"], m["padding"])
+        assert rel_err(torch.from_numpy(y), g.t(f"conv{i}.y")) < 2e-6, m
+    y = OC.conv_transpose2d(g.t("convT.x").numpy(), g.t("convT.w").numpy(), 2)
+    assert rel_err(torch.from_numpy(y), g.t("convT.y")) < 2e-6
+    for m in g.json("meta")["mod"]:
+        i = m["i"]
+        s = O.equal_linear(g.t(f"mod{i}.style"), g.t(f"mod{i}.mw"), g.t(f"mod{i}.mb")).numpy()
+        y = OC.modulated_conv2d(g.t(f"mod{i}.x").numpy(), s, g.t(f"mod{i}.w").numpy(), True, m["up"])
+        if m["up"]:
+            y = OC.upfirdn2d(y, k1 * 4, pad=(1, 1))
+        assert rel_err(torch.from_numpy(y), g.t(f"mod{i}.y")) < 5e-6, m

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv family on the layer shapes that carry the step's FLOPs.
+Prints TFLOP/s per (shape, pass).  Usage on the GPU box: python tools/bench_igemm.py [--batch 32] [--reps 10]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ideas_amd.op.conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw  # noqa: E402
+from ideas_amd.op.conv_plan import ConvGeom, convT_out_size  # noqa: E402
+
+CL = torch.channels_last
+
+# name, Cin, Cout, k, stride, pad, reflect, H(in), batch multiplier, modulated, kind
+SHAPES = [
+    ("G.L7.conv2 mod 128->128 @256", 128, 128, 3, 1, 1, False, 256, 1, True, "conv"),
+    ("G.L6.conv2 mod 256->256 @128", 256, 256, 3, 1, 1, False, 128, 1, True, "conv"),
+    ("G.L5.conv2 mod 512->512 @64", 512, 512, 3, 1, 1, False, 64, 1, True, "conv"),
+    ("G.L3.conv2 mod 512->512 @16", 512, 512, 3, 1, 1, False, 16, 1, True, "conv"),
+    ("G.L7.conv1 up 256->128 @128", 256, 128, 3, 2, 0, False, 128, 1, True, "convT"),
+    ("G.L5.conv1 up 512->512 @32", 512, 512, 3, 2, 0, False, 32, 1, True, "convT"),
+    ("Dreal.1.conv1 64->128 @256 (3B)", 64, 128, 3, 1, 1, False, 256, 3, False, "conv"),
+    ("Dreal.1.conv2 128->128 s2 @257", 128, 128, 3, 2, 0, False, 257, 3, False, "conv"),
+    ("Dreal.3.conv1 256->512 @64 (3B)", 256, 512, 3, 1, 1, False, 64, 3, False, "conv"),
+    ("E.1.conv1 32->64 refl @256", 32, 64, 3, 1, 1, True, 256, 1, False, "conv"),
+    ("E.2.conv1 64->128 refl @128", 64, 128, 3, 1, 1, True, 128, 1, False, "conv"),
+    ("skip 1x1 s2 64->128 @255 (3B)", 64, 128, 1, 2, 0, False, 255, 3, False, "conv"),
+    ("1x1 512->512 @16", 512, 512, 1, 1, 0, False, 16, 1, False, "conv"),
+    ("to_rgb 128->3 @256", 128, 3, 1, 1, 0, False, 256, 1, False, "conv"),
+    ("Dco.1.conv1 32->64 @64 (8B patches)", 32, 64, 3, 1, 1, False, 64, 8, False, "conv"),
+    ("E.tex.1 1024->2048 s2 @9", 1024, 2048, 3, 2, 0, False, 9, 1, False, "conv"),
+]
+
+
+def timeit(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    tot_f = tot_t = 0.0
+    for (name, ci, co, k, s, p, refl, H, bm, mod, kind) in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        B = a.batch * bm
+        g = ConvGeom(k, k, s, p, refl)
+        if kind == "conv":
+            x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=CL)
+            w = torch.randn(co, ci, k, k, device=dev).contiguous(memory_format=CL)
+            oh, ow = g.out_size(H, H)
+            gy = torch.randn(B, co, oh, ow, device=dev).contiguous(memory_format=CL)
+            lin = (torch.rand(B, ci, device=dev) + 0.5) if mod else None
+            lout = (torch.rand(B, co, device=dev) + 0.5) if mod else None
+            flops = 2.0 * B * oh * ow * ci * co * k * k
+            passes = {
+                "fwd": lambda: conv_fwd_raw(x, w, g, 0.1, lin, lout),
+                "dgrad": (lambda: conv_dgrad_raw(gy, w, ConvGeom(k, k, s, p, False), (H, H), 0.1, lout, lin)) if not refl else None,
+                "wgrad": lambda: conv_wgrad_raw(gy, x, g, w.shape, 0.1, lin, lout),
+            }
+        else:  # transposed conv: weight read as conv weight [O'=ci, I'=co]
+            x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=CL)
+            wt = torch.randn(ci, co, k, k, device=dev).contiguous(memory_format=CL)
+            oh, ow = convT_out_size(H, H, g)
+            gy = torch.randn(B, co, oh, ow, device=dev).contiguous(memory_format=CL)
+            lin = (torch.rand(B, ci, device=dev) + 0.5) if mod else None
+            lout = (torch.rand(B, co, device=dev) + 0.5) if mod else None
+            flops = 2.0 * B * H * H * ci * co * k * k
+            passes = {
+                "fwd": lambda: conv_dgrad_raw(x, wt, g, (oh, ow), 0.1, lin, lout),
+                "dgrad": lambda: conv_fwd_raw(gy, wt, g, 0.1, lout, lin),
+                "wgrad": lambda: conv_wgrad_raw(x, gy, g, wt.shape, 0.1, lout, lin),
+            }
+        row = []
+        for pn, fn in passes.items():
+            if fn is None:
+                row.append(f"{pn}    -   ")
+                continue
+            ms = timeit(fn, a.reps)
+            tot_f += flops
+            tot_t += ms
+            row.append(f"{pn} {flops / ms / 1e9:6.1f} TF/s {ms:7.3f} ms")
+        print(f"{name:38s} B={B:4d} {flops / 1e9:8.1f} GF | " + " | ".join(row), flush=True)
+        del x, gy
+        torch.cuda.empty_cache()
+    print(f"aggregate: {tot_f / tot_t / 1e9:.1f} TF/s over {tot_t:.1f} ms")
+
+
+if __name__ == "__main__":
+    main()
