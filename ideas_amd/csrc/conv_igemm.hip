@@ -49,8 +49,8 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v) {
 // =====================================================================================================
 // forward family
 // =====================================================================================================
-template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ y, const float* __restrict__ x,
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT, bool WIDE>
+__global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_igemm_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                             const float* __restrict__ wmat,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ out_scale,
@@ -145,11 +145,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
             rb[j] = *reinterpret_cast<const float4*>(ok ? b_ptr[j] + (int64_t)kt * BK : wmat);
             okb[j] = ok;
         }
-        // advance the walker by one K-step
-        k_ci += BK;
-        while (k_ci >= p.Cin) {
-            k_ci -= p.Cin;
-            if (++k_tx == p.TX) { k_tx = 0; ++k_ty; }
+        // advance the walker by one K-step (no branches: the whole K loop stays one basic block)
+        if (WIDE) {   // Cin >= 16: at most one tap boundary per step
+            k_ci += BK;
+            const bool wrap = k_ci >= p.Cin;
+            k_ci -= wrap ? p.Cin : 0;
+            k_tx += wrap ? 1 : 0;
+            const bool wrap2 = k_tx == p.TX;
+            k_tx = wrap2 ? 0 : k_tx;
+            k_ty += wrap2 ? 1 : 0;
+        } else {
+            const int k = (kt + 1) * BK + kq * 4;
+            const int tap = k / p.Cin;
+            k_ci = k - tap * p.Cin;
+            k_ty = tap / p.TX;
+            k_tx = tap - k_ty * p.TX;
         }
     };
     auto lstore = [&](int buf) {
@@ -181,13 +191,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Pipeline (one barrier per K-step, loop body = ONE basic block):
+    //   top of step t : registers hold tile t+1 (issued a whole step ago) -> scale/mask -> LDS[buf^1];
+    //                   issue the loads of tile t+2 into the same registers;
+    //   then          : fragments of tile t from LDS[buf], 8*MT*NT MFMAs;  barrier.
+    // Loads beyond K are predicated off (clamped address, zeroed), so no bounds branch is needed.
     const int nk = (K + BK - 1) / BK;
     gload(0);
     lstore(0);
+    gload(1);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        lstore(buf ^ 1);
+        gload(kt + 2);
         float4 fa[MT][2], fb[NT][2];
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
@@ -215,8 +232,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the consumption of the prefetched tile behind the MFMAs
-        if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -269,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(float* __restrict__ 
 //   (split-K); partial tiles are combined with f32 atomics into the caller-zeroed gw.
 // =====================================================================================================
 template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
+__global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ out_scale, ideas_conv_params p,
@@ -469,9 +484,14 @@ int launch_fwd_cfg(void* y, const void* x, const void* wmat, const float* in_sca
     const int tn = (int)ideas_cdiv(p->Cout, BN_);
     if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
     auto go = [&](auto sc, auto rf) {
-        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
-                           dim3((unsigned)(tm * tn)), dim3(256), 0, stream, (float*)y, (const float*)x,
-                           (const float*)wmat, in_scale, out_scale, bias, (const float*)resid, *p, tn);
+        if (p->Cin >= BK)
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value, true>),
+                               dim3((unsigned)(tm * tn)), dim3(256), 0, stream, (float*)y, (const float*)x,
+                               (const float*)wmat, in_scale, out_scale, bias, (const float*)resid, *p, tn);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value, false>),
+                               dim3((unsigned)(tm * tn)), dim3(256), 0, stream, (float*)y, (const float*)x,
+                               (const float*)wmat, in_scale, out_scale, bias, (const float*)resid, *p, tn);
     };
     using T = std::true_type;
     using F = std::false_type;
@@ -489,13 +509,42 @@ int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_s
     const int tm = (int)ideas_cdiv(p->Cout, BM_);
     const int tn = (int)ideas_cdiv(Ktot, BN_);
     const int64_t tiles = (int64_t)tm * tn;
-    int64_t splits = ideas_cdiv(1024, tiles);
-    const int64_t max_splits = ideas_cdiv(P, 8 * BK);
-    if (splits > max_splits) splits = max_splits;
+    // split-K sizing: the grid should be a whole number of "waves" of resident blocks, otherwise the last,
+    // partially filled wave costs as much as a full one (1026 blocks on 1024 slots ran 2x the time).
+    const bool sc_ = in_scale && out_scale;
+    static int occ_cache[2] = {0, 0};
+    if (!occ_cache[sc_]) {
+        int occ = 0;
+        hipError_t e = sc_ ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_kernel<WM, WN, MT, NT, true, false>, 256, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_kernel<WM, WN, MT, NT, false, false>, 256, 0);
+        occ_cache[sc_] = (e == hipSuccess && occ > 0) ? occ : 2;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int64_t slots = (int64_t)occ_cache[sc_] * n_cu;
+    const int64_t max_splits = ideas_cdiv(P, 16 * BK);          // keep >= 16 pipeline steps per block
+    int64_t splits = (2 * slots) / tiles;                        // aim at two full waves of blocks
     if (splits < 1) splits = 1;
+    if (splits > max_splits) splits = max_splits;
     if (splits > 65535) splits = 65535;
-    const int64_t per = ideas_cdiv(ideas_cdiv(P, splits), BK) * BK;
+    int64_t per = ideas_cdiv(ideas_cdiv(P, splits), BK) * BK;
     splits = ideas_cdiv(P, per);
+    // rounding `per` up to BK can shave a split off; re-balance so the block count stays a multiple of the slots
+    {
+        const int64_t blocks = tiles * splits;
+        const int64_t waves = blocks / slots;
+        if (waves >= 1 && blocks % slots) {
+            const int64_t want = (waves * slots) / tiles;        // largest split count giving whole waves
+            if (want >= 1) {
+                per = ideas_cdiv(ideas_cdiv(P, want), BK) * BK;
+                splits = ideas_cdiv(P, per);
+            }
+        }
+    }
     auto go = [&](auto sc, auto rf) {
         hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
                            dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const float*)gy,
@@ -503,7 +552,7 @@ int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_s
     };
     using T = std::true_type;
     using F = std::false_type;
-    const bool sc = in_scale && out_scale;
+    const bool sc = sc_;
     if (sc) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
     else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
     return ideas_launch_status();

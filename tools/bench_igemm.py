@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: same work, lower power)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     tot_f = tot_t = 0.0
@@ -60,6 +61,8 @@ def main():
             continue
         B = a.batch * bm
         g = ConvGeom(k, k, s, p, refl)
+        if a.zeros:
+            torch.randn = lambda *sh, **kw: torch.zeros(*sh, **kw)
         if kind == "conv":
             x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=CL)
             w = torch.randn(co, ci, k, k, device=dev).contiguous(memory_format=CL)
