@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(float* __restrict__ y,
                 }
             }
         }
-        float v = acc * p.gain;
-        if (out_scale) v *= out_scale[(int64_t)b * p.Cout + o];
-        if (bias) v += bias[o];
+        float v = __fmul_rn(acc, p.gain);
+        if (out_scale) v = __fmul_rn(v, out_scale[(int64_t)b * p.Cout + o]);
+        if (bias) v = __fadd_rn(v, bias[o]);
         if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
         const int64_t yi = (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + o;
         if (resid) v = (v + resid[yi]) * p.resid_gain;
@@ -90,6 +90,73 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(float* __restrict__ g
     }
 }
 
+// ---- pointwise (1x1, stride 1, no padding) fast paths -------------------------------------------------
+// The tiny-K layers on the path are all pointwise: from-RGB (3 -> 32/64), Gstru's N -> 32, to_rgb's input
+// gradient (3 -> 128), Ex's last layer.  A thread owns ONE output channel (weights in registers), walks pixels
+// with a fixed stride and writes coalesced along channels; x is a broadcast load.  Pure HBM streaming.
+template <int KMAX>
+__global__ __launch_bounds__(256) void pointwise_smallk_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const float* __restrict__ resid, int64_t P, int Cin, int Cout,
+                                                               float gain, int act, float alpha, float act_gain,
+                                                               float resid_gain, int accumulate) {
+    const int groups = blockDim.x / Cout;            // pixel lanes per block
+    const int o = threadIdx.x % Cout, grp = threadIdx.x / Cout;
+    if (grp >= groups) return;
+    float wr[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) wr[k] = k < Cin ? w[(int64_t)o * Cin + k] : 0.f;
+    const float bv = bias ? bias[o] : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * groups;
+    for (int64_t pp = (int64_t)blockIdx.x * groups + grp; pp < P; pp += stride) {
+        const float* xp = x + pp * Cin;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < Cin) acc = fmaf(xp[k], wr[k], acc);
+        float v = __fadd_rn(__fmul_rn(acc, gain), bv);   // no FMA contraction: bitwise the unfused conv -> bias_act
+        if (act) v = (v > 0.f ? v : v * alpha) * act_gain;
+        const int64_t yi = pp * Cout + o;
+        if (resid) v = (v + resid[yi]) * resid_gain;
+        if (accumulate) y[yi] += v; else y[yi] = v;
+    }
+}
+
+// gw[o][ci] += gain * sum_p gy[p][o] * x[p][ci] with min(Cin, Cout) <= 8.  WIDE_OUT: threads span o (gy coalesced,
+// x broadcast, Cin accumulators); otherwise threads span ci (x coalesced, gy broadcast, Cout accumulators).
+template <int SMALL, bool WIDE_OUT>
+__global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
+                                                                    const float* __restrict__ x, int64_t P, int Cin, int Cout,
+                                                                    float gain, int64_t pix_per_block) {
+    const int wide = WIDE_OUT ? Cout : Cin, small = WIDE_OUT ? Cin : Cout;
+    const int groups = blockDim.x / wide;
+    const int c = threadIdx.x % wide, grp = threadIdx.x / wide;
+    if (grp >= groups) return;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
+    float acc[SMALL];
+#pragma unroll
+    for (int k = 0; k < SMALL; ++k) acc[k] = 0.f;
+    for (int64_t pp = p0 + grp; pp < p1; pp += groups) {
+        const float a = WIDE_OUT ? gy[pp * Cout + c] : x[pp * Cin + c];
+        const float* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
+#pragma unroll
+        for (int k = 0; k < SMALL; ++k)
+            if (k < small) acc[k] = fmaf(a, bp[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < SMALL; ++k)
+        if (k < small) {
+            const int o = WIDE_OUT ? c : k, ci = WIDE_OUT ? k : c;
+            atomicAdd(&gw[(int64_t)o * Cin + ci], acc[k] * gain);
+        }
+}
+
+bool is_pointwise(const ideas_conv_params* p) {
+    return p->TY == 1 && p->TX == 1 && p->sy == 1 && p->sx == 1 && p->offy == 0 && p->offx == 0 && p->osy == 1 &&
+           p->osx == 1 && p->ooy == 0 && p->oox == 0 && p->IH == p->OH && p->IW == p->OW && p->YH == p->OH && p->YW == p->OW;
+}
+
 int check_conv(const ideas_conv_params* p) {
     if (!p) return IDEAS_E_NULL;
     if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->YH <= 0 || p->YW <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;
@@ -110,6 +177,17 @@ extern "C" int ideas_conv_direct(void* y, const void* x, const void* wmat, const
     if (!y || !x || !wmat) return IDEAS_E_NULL;
     int rc = check_conv(p);
     if (rc) return rc;
+    if (is_pointwise(p) && !in_scale && !out_scale && p->Cin <= 8 && p->Cout <= 256) {
+        const int64_t P = (int64_t)p->B * p->OH * p->OW;
+        const int groups = 256 / p->Cout;
+        int64_t grid = ideas_cdiv(P, (int64_t)groups * 8);
+        if (grid > 8192) grid = 8192;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(pointwise_smallk_kernel<8>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float*)y,
+                           (const float*)x, (const float*)wmat, bias, (const float*)resid, P, p->Cin, p->Cout, p->gain,
+                           p->act, p->alpha, p->act_gain, p->resid_gain, p->accumulate);
+        return ideas_launch_status();
+    }
     const int64_t total = (int64_t)p->B * p->OH * p->OW * p->Cout;
     int64_t grid = ideas_cdiv(total, 256);
     if (grid > 65536) grid = 65536;
@@ -125,6 +203,19 @@ extern "C" int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x,
     int rc = check_conv(p);
     if (rc) return rc;
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
+    if (is_pointwise(p) && !in_scale && !out_scale && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256) {
+        int64_t blocks = ideas_cdiv(P, 512);
+        if (blocks > 4096) blocks = 4096;
+        const int64_t per = ideas_cdiv(P, blocks);
+        blocks = ideas_cdiv(P, per);
+        if (p->Cin <= 8 && p->Cin <= p->Cout)
+            hipLaunchKernelGGL((pointwise_small_wgrad_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0,
+                               (hipStream_t)stream, gw, (const float*)gy, (const float*)x, P, p->Cin, p->Cout, p->gain, per);
+        else
+            hipLaunchKernelGGL((pointwise_small_wgrad_kernel<8, false>), dim3((unsigned)blocks), dim3(256), 0,
+                               (hipStream_t)stream, gw, (const float*)gy, (const float*)x, P, p->Cin, p->Cout, p->gain, per);
+        return ideas_launch_status();
+    }
     int64_t blocks = ideas_cdiv(P, 256);
     if (blocks > 2048) blocks = 2048;
     const int64_t per = ideas_cdiv(P, blocks);

@@ -57,14 +57,25 @@ class EqualConv2d(nn.Module):
         self.padding = padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, input, reflect_pad: int = 0, act: Optional[FusedLeakyReLU] = None):
-        """``act``: the FusedLeakyReLU that follows in the ConvLayer — folded into the conv epilogue."""
+    def forward(self, input, reflect_pad: int = 0, act: Optional[FusedLeakyReLU] = None, post_gain: float = 1.0,
+                resid: Optional[torch.Tensor] = None):
+        """``act``: the FusedLeakyReLU that follows in the ConvLayer — folded into the conv epilogue.
+        ``post_gain``: extra scalar on the layer output (the residual blocks' 1/sqrt(2)), folded into the
+        activation gain / conv gain.  ``resid``: residual branch added in the epilogue (no-grad passes only)."""
         pad, refl = (reflect_pad, True) if reflect_pad else (self.padding, False)
         if act is not None and self.bias is None:
             return conv2d_bias_act(input, self.weight, act.bias, stride=self.stride, padding=pad, reflect=refl,
-                                   gain=self.scale, negative_slope=act.negative_slope, scale=act.scale)
+                                   gain=self.scale, negative_slope=act.negative_slope, scale=act.scale * post_gain,
+                                   resid=resid)
+        if resid is not None:
+            raise RuntimeError("resid is only supported on the fused conv + activation path")
+        if act is None:
+            if self.bias is not None and post_gain != 1.0:
+                raise RuntimeError("post_gain with a conv bias is not used on this path")
+            return conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl,
+                          gain=self.scale * post_gain)
         out = conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl, gain=self.scale)
-        return out if act is None else act(out)
+        return fused_leaky_relu(out, act.bias, act.negative_slope, act.scale * post_gain)
 
     def __repr__(self):
         o, i, k, _ = self.weight.shape
@@ -125,14 +136,16 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 
-    def forward(self, input, style, act: Optional[FusedLeakyReLU] = None):
+    def forward(self, input, style, act: Optional[FusedLeakyReLU] = None, post_gain: float = 1.0,
+                resid: Optional[torch.Tensor] = None):
         s = self.modulation(style)
         fir = self.blur.kernel if self.upsample else None
         if act is None:
             return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
                                     eps=self.eps)
         return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
-                                eps=self.eps, act_bias=act.bias, negative_slope=act.negative_slope, act_scale=act.scale)
+                                eps=self.eps, act_bias=act.bias, negative_slope=act.negative_slope,
+                                act_scale=act.scale * post_gain, resid=resid)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -147,5 +160,6 @@ class StyledConv_without_noise(nn.Module):
                                     blur_kernel=blur_kernel, demodulate=demodulate)
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
-        return self.conv(input, style, act=self.activate)   # bias + leaky-ReLU folded into the conv epilogue
+    def forward(self, input, style, noise=None, post_gain: float = 1.0, resid: Optional[torch.Tensor] = None):
+        # bias + leaky-ReLU (and, for the block's last conv, the 1/sqrt(2) and the residual) folded into the conv epilogue
+        return self.conv(input, style, act=self.activate, post_gain=post_gain, resid=resid)

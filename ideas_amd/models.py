@@ -39,8 +39,8 @@ class EqualConvTranspose2d(nn.Module):
         self.padding = padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, input):
-        return conv_transpose2d(input, self.weight, self.bias, stride=self.stride, gain=self.scale)
+    def forward(self, input, post_gain: float = 1.0):
+        return conv_transpose2d(input, self.weight, self.bias, stride=self.stride, gain=self.scale * post_gain)
 
     def __repr__(self):
         i, o, k, _ = self.weight.shape
@@ -92,7 +92,10 @@ class ConvLayer(nn.Sequential):
         super().__init__(*mods)
         self.padding = conv_pad
 
-    def forward(self, input):
+    def forward(self, input, post_gain: float = 1.0, resid=None):
+        """``post_gain`` scales the layer output (folded into the conv / activation gain — every op after the conv is
+        linear or the scaled leaky-ReLU, so the fold is exact up to rounding); ``resid`` is added in the last conv's
+        epilogue (no-grad passes only)."""
         x = input
         mods = list(self)
         i = 0
@@ -105,18 +108,31 @@ class ConvLayer(nn.Sequential):
                 m = mods[i]
             if isinstance(m, EqualConv2d):
                 act = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], FusedLeakyReLU) else None
-                x = m(x, reflect_pad=refl, act=act)            # bias + leaky-ReLU folded into the conv epilogue
-                i += 2 if act is not None else 1
+                nxt = i + (2 if act is not None else 1)
+                if nxt < len(mods) and post_gain != 1.0:
+                    raise RuntimeError("post_gain needs the conv (+activation) to end the layer")
+                x = m(x, reflect_pad=refl, act=act, post_gain=post_gain, resid=resid)
+                i = nxt
+                continue
+            if isinstance(m, EqualConvTranspose2d):
+                x = m(x, post_gain=post_gain)                  # the blur that follows is linear
+                i += 1
                 continue
             x = m(x)
             i += 1
         return x
 
 
-def _merge(out, skip):
-    """(out + skip) / sqrt(2) as one fused op."""
-    return torch.add(out, skip).mul_(_INV_SQRT2) if not (out.requires_grad or skip.requires_grad) \
-        else (out + skip) * _INV_SQRT2
+def _res_merge(block, body, last, input):
+    """(body(input) + skip(input)) / sqrt(2) with the 1/sqrt(2) folded into both branches' gains (no multiply pass),
+    and — when no graph is being built — the add folded into the last conv's epilogue as well."""
+    if block.skip is None:
+        return (last(body(input)) + input) * _INV_SQRT2
+    skip = block.skip(input, post_gain=_INV_SQRT2)
+    h = body(input)
+    if not torch.is_grad_enabled():
+        return last(h, post_gain=_INV_SQRT2, resid=skip)
+    return last(h, post_gain=_INV_SQRT2) + skip
 
 
 class StyledResBlock(nn.Module):
@@ -131,9 +147,7 @@ class StyledResBlock(nn.Module):
             self.skip = None
 
     def forward(self, input, style, noise=None):
-        out = self.conv2(self.conv1(input, style), style)
-        skip = input if self.skip is None else self.skip(input)
-        return _merge(out, skip)
+        return _res_merge(self, lambda x: self.conv1(x, style), lambda h, **kw: self.conv2(h, style, **kw), input)
 
 
 class ResBlock(nn.Module):
@@ -151,9 +165,7 @@ class ResBlock(nn.Module):
             self.skip = None
 
     def forward(self, input):
-        out = self.conv2(self.conv1(input))
-        skip = input if self.skip is None else self.skip(input)
-        return _merge(out, skip)
+        return _res_merge(self, self.conv1, self.conv2, input)
 
 
 class DisentanglementEncoder(nn.Module):

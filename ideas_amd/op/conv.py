@@ -218,10 +218,16 @@ class _ConvBiasAct(Function):
 
 def conv2d_bias_act(input: torch.Tensor, weight: torch.Tensor, act_bias: torch.Tensor, stride: int = 1, padding: int = 0,
                     reflect: bool = False, gain: float = 1.0, negative_slope: float = 0.2,
-                    scale: float = 2 ** 0.5) -> torch.Tensor:
-    """``fused_leaky_relu(gain * conv2d(input, weight), act_bias, negative_slope, scale)`` in one kernel."""
+                    scale: float = 2 ** 0.5, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``fused_leaky_relu(gain * conv2d(input, weight), act_bias, negative_slope, scale)`` in one kernel.
+    ``resid`` (inference only): the residual branch, added in the same epilogue."""
     _lib.require_cuda(input, weight, act_bias)
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
+    if resid is not None:
+        if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or act_bias.requires_grad or resid.requires_grad):
+            raise RuntimeError("conv2d_bias_act(resid=...) is the no-grad fast path")
+        return conv_fwd_raw(input, weight, g, float(gain), bias=act_bias.contiguous(), act=True, act_gain=float(scale),
+                            alpha=float(negative_slope), resid=resid, resid_gain=1.0)
     return _ConvBiasAct.apply(input, weight, act_bias, g, float(gain), float(negative_slope), float(scale))
 
 

@@ -160,7 +160,7 @@ class _ModConvAct(Function):
 def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, demodulate: bool = True,
                      upsample: bool = False, fir: Optional[torch.Tensor] = None, eps: float = 1e-8,
                      act_bias: Optional[torch.Tensor] = None, negative_slope: float = 0.2,
-                     act_scale: float = 2 ** 0.5) -> torch.Tensor:
+                     act_scale: float = 2 ** 0.5, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x`` [B,Cin,H,W]; ``weight`` [1,Cout,Cin,k,k] (the reference's parameter); ``style`` [B,Cin] = the
     already-affine-transformed modulation (stylegan2/model.py:239).  ``fir`` = the 4x4 blur (
     here) used after the stride-2 transposed conv (stylegan2/model.py:202-208, 258-261); it already carries the x4
@@ -174,6 +174,13 @@ def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
         wsq = (w * w).sum(dim=(2, 3)) * (scale * scale)
         d = _Demod.apply(style, wsq, eps)
     fuse_act = act_bias is not None and not upsample and demodulate and cout % 4 == 0
+    if resid is not None:
+        if not fuse_act or torch.is_grad_enabled():
+            raise RuntimeError("modulated_conv2d(resid=...) is the no-grad fast path of the fused same-resolution conv")
+        k_ = w.shape[2]
+        return conv_fwd_raw(x, w, ConvGeom(k_, k_, 1, k_ // 2, False), scale, lin=style.contiguous(), lout=d.contiguous(),
+                            bias=act_bias.contiguous(), act=True, act_gain=float(act_scale), alpha=float(negative_slope),
+                            resid=resid, resid_gain=1.0)
     if fuse_act:
         return _ModConvAct.apply(x, w, style, d, act_bias, scale, float(negative_slope), float(act_scale))
     y = _ModConv.apply(x, w, style, d, upsample, scale)
