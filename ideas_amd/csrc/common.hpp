@@ -27,3 +27,15 @@ __device__ __forceinline__ int reflect_coord(int i, int n) {
     if (i >= n) i = 2 * n - 2 - i;
     return i;
 }
+
+// a*b then +c with TWO roundings.  hipcc contracts `a*b + c` into one FMA by default (and __fmul_rn/__fadd_rn are
+// plain operators in HIP), which would make a fused conv epilogue differ by 1 ulp from conv -> fused_bias_act.
+__device__ __forceinline__ float mul_then_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float m = a * b;
+    return m + c;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}

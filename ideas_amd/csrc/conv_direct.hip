@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(float* __restrict__ y,
                 }
             }
         }
-        float v = __fmul_rn(acc, p.gain);
-        if (out_scale) v = __fmul_rn(v, out_scale[(int64_t)b * p.Cout + o]);
-        if (bias) v = __fadd_rn(v, bias[o]);
+        float v = mul_rn(acc, p.gain);
+        if (out_scale) v = mul_rn(v, out_scale[(int64_t)b * p.Cout + o]);
+        v = mul_then_add(v, 1.0f, bias ? bias[o] : 0.f);
         if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
         const int64_t yi = (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + o;
         if (resid) v = (v + resid[yi]) * p.resid_gain;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void pointwise_smallk_kernel(float* __restrict
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < Cin) acc = fmaf(xp[k], wr[k], acc);
-        float v = __fadd_rn(__fmul_rn(acc, gain), bv);   // no FMA contraction: bitwise the unfused conv -> bias_act
+        float v = mul_then_add(acc, gain, bv);   // no FMA contraction: bitwise the unfused conv -> bias_act
         if (act) v = (v > 0.f ? v : v * alpha) * act_gain;
         const int64_t yi = pp * Cout + o;
         if (resid) v = (v + resid[yi]) * resid_gain;
@@ -128,28 +128,38 @@ template <int SMALL, bool WIDE_OUT>
 __global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
                                                                     const float* __restrict__ x, int64_t P, int Cin, int Cout,
                                                                     float gain, int64_t pix_per_block) {
+    __shared__ float s_red[256 * 8];   // [wide][SMALL] block-level partial sums
     const int wide = WIDE_OUT ? Cout : Cin, small = WIDE_OUT ? Cin : Cout;
     const int groups = blockDim.x / wide;
     const int c = threadIdx.x % wide, grp = threadIdx.x / wide;
-    if (grp >= groups) return;
-    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
-    const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
-    float acc[SMALL];
+    for (int i = threadIdx.x; i < wide * SMALL; i += blockDim.x) s_red[i] = 0.f;
+    __syncthreads();
+    if (grp < groups) {
+        const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+        const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
+        float acc[SMALL];
 #pragma unroll
-    for (int k = 0; k < SMALL; ++k) acc[k] = 0.f;
-    for (int64_t pp = p0 + grp; pp < p1; pp += groups) {
-        const float a = WIDE_OUT ? gy[pp * Cout + c] : x[pp * Cin + c];
-        const float* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
+        for (int k = 0; k < SMALL; ++k) acc[k] = 0.f;
+        for (int64_t pp = p0 + grp; pp < p1; pp += groups) {
+            const float a = WIDE_OUT ? gy[pp * Cout + c] : x[pp * Cin + c];
+            const float* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
+#pragma unroll
+            for (int k = 0; k < SMALL; ++k)
+                if (k < small) acc[k] = fmaf(a, bp[k], acc[k]);
+        }
 #pragma unroll
         for (int k = 0; k < SMALL; ++k)
-            if (k < small) acc[k] = fmaf(a, bp[k], acc[k]);
+            if (k < small) atomicAdd(&s_red[c * SMALL + k], acc[k]);   // LDS: fold the pixel groups of this block
     }
-#pragma unroll
-    for (int k = 0; k < SMALL; ++k)
+    __syncthreads();
+    // one global atomic per (block, output element): few blocks x few outputs, so no hot-address serialisation
+    for (int i = threadIdx.x; i < wide * SMALL; i += blockDim.x) {
+        const int cc = i / SMALL, k = i % SMALL;
         if (k < small) {
-            const int o = WIDE_OUT ? c : k, ci = WIDE_OUT ? k : c;
-            atomicAdd(&gw[(int64_t)o * Cin + ci], acc[k] * gain);
+            const int o = WIDE_OUT ? cc : k, ci = WIDE_OUT ? k : cc;
+            atomicAdd(&gw[(int64_t)o * Cin + ci], s_red[i] * gain);
         }
+    }
 }
 
 bool is_pointwise(const ideas_conv_params* p) {
@@ -205,7 +215,7 @@ extern "C" int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x,
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
     if (is_pointwise(p) && !in_scale && !out_scale && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256) {
         int64_t blocks = ideas_cdiv(P, 512);
-        if (blocks > 4096) blocks = 4096;
+        if (blocks > 1024) blocks = 1024;
         const int64_t per = ideas_cdiv(P, blocks);
         blocks = ideas_cdiv(P, per);
         if (p->Cin <= 8 && p->Cin <= p->Cout)

@@ -265,9 +265,9 @@ __global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_igemm_kernel(float* _
                 const int row = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int64_t off = row_off[row];
                 if (off < 0) continue;
-                float v = __fmul_rn(acc[a][b][r], p.gain);   // explicit roundings: no FMA contraction, so the fused
-                if (out_scale) v = __fmul_rn(v, out_scale[(int64_t)row_b[row] * p.Cout + n]);
-                v = __fadd_rn(v, bv);                        // epilogue is bitwise conv -> fused_bias_act
+                float v = mul_rn(acc[a][b][r], p.gain);      // separate roundings (no FMA contraction): the fused
+                if (out_scale) v = mul_rn(v, out_scale[(int64_t)row_b[row] * p.Cout + n]);
+                v = mul_then_add(v, 1.0f, bv);               // epilogue is bitwise conv -> fused_bias_act
                 if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
                 if (resid) v = (v + resid[off + n]) * p.resid_gain;
                 if (p.accumulate) y[off + n] += v; else y[off + n] = v;

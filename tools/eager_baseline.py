@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Stock PyTorch-ROCm eager comparator: the oracle's restatement of the reference step (composite torch ops,
+MIOpen convolutions, per-sample grouped modulated convs exactly like the reference) timed on cuda:0.
+Benchmark-side tool only (BASELINE.md §3 'GPU comparators'); the product never imports the oracle."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle.torch_ref as O  # noqa: E402
+from ideas_amd import train_step as TS  # noqa: E402
+from ideas_amd.models import init_model  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--channels-last", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    torch.backends.cudnn.benchmark = True     # the reference sets this (train.py:327)
+    R = 256
+    args = TS.default_args(image_size=R)
+    torch.manual_seed(0)
+    nets, opt_params = {}, {}
+    for n in ("E", "G", "Gstru", "Ex", "Dreal", "Dco", "Ddist"):
+        m = init_model(TS.NET_CLASSES[n], args)
+        nets[n] = {k: v.detach().contiguous().to(dev).requires_grad_(v.is_floating_point() and not k.endswith("kernel"))
+                   for k, v in m.state_dict().items()}
+    plist = lambda names: [p for n in names for p in nets[n].values() if p.requires_grad]
+    d_params, g_params, ex_params = plist(("Dreal", "Dco", "Ddist")), plist(("E", "G", "Gstru")), plist(("Ex",))
+    r = 16 / 17
+    d_opt = torch.optim.Adam(d_params, lr=0.002 * r, betas=(0.0, 0.99 ** r))
+    g_opt = torch.optim.Adam(g_params, lr=0.002, betas=(0.0, 0.99))
+    ex_opt = torch.optim.Adam(ex_params, lr=0.002, betas=(0.0, 0.99))
+    cfg, sargs = O.Cfg(image_size=R), O.StepArgs()
+    B = a.batch
+    X = (torch.rand(B, 3, R, R) * 2 - 1).to(dev)
+    if a.channels_last:
+        X = X.contiguous(memory_format=torch.channels_last)
+    random.seed(0)
+
+    def step():
+        s = R // 16
+        dr = O.StepDraws(Z_d=(torch.rand(B, 1, s, s) * 2 - 1).to(dev), T2_d=torch.rand(B, 2048, device=dev) * 2 - 1,
+                         Z_g=(torch.rand(B, 1, s, s) * 2 - 1).to(dev), T2_g=torch.rand(B, 2048, device=dev) * 2 - 1,
+                         boxes_d_fake=O.draw_boxes(R, R, 8), boxes_d_real=O.draw_boxes(R, R, 8),
+                         boxes_d_ref=O.draw_boxes(R, R, 32), boxes_g_fake=O.draw_boxes(R, R, 8),
+                         boxes_g_ref=O.draw_boxes(R, R, 32))
+        total, _, _ = O.d_phase(nets, cfg, sargs, X, dr)
+        gs = torch.autograd.grad(total, d_params, allow_unused=True)
+        for p, g in zip(d_params, gs):
+            p.grad = g
+        d_opt.step()
+        for n in ("Dreal", "Dco", "Ddist"):
+            for p in nets[n].values():
+                p.requires_grad_(False)
+        total, ex_loss, _, _ = O.g_phase(nets, cfg, sargs, X, dr, 1)
+        ge = torch.autograd.grad(ex_loss, ex_params, retain_graph=True)
+        gg = torch.autograd.grad(total, g_params, allow_unused=True)
+        for p, g in zip(g_params, gg):
+            p.grad = g
+        g_opt.step()
+        for p, g in zip(ex_params, ge):
+            p.grad = g
+        ex_opt.step()
+        for n in ("Dreal", "Dco", "Ddist"):
+            for k, p in nets[n].items():
+                p.requires_grad_(p.is_floating_point() and not k.endswith("kernel"))
+
+    t_w = time.perf_counter()
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t_w = time.perf_counter() - t_w
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"eager_gpu_images_per_sec": round(B * a.steps / dt, 3), "ms_per_step": round(dt / a.steps * 1e3, 1),
+                      "batch": B, "steps": a.steps, "warmup_s": round(t_w, 1), "channels_last": a.channels_last,
+                      "note": "oracle step (no R1, elided 2nd backward, no EMA) on cuda:0, MIOpen convs, torch %s" % torch.__version__,
+                      "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+
+
+if __name__ == "__main__":
+    main()
