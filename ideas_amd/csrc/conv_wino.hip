@@ -1,0 +1,265 @@
+// 3x3 stride-1 pad-1 convolution with a 1-D Winograd F(2,3) transform along x, on the f32 MFMA pipe, NHWC.
+//
+// The 3x3/s1 layers (Generator conv2s and same-resolution conv1s, every ResBlock conv1 of E / Dreal / Dco and
+// their input gradients) carry ~2/3 of the step's FLOPs and the step is MFMA-bound, so the lever left once the
+// implicit GEMM sits at ~0.75 of peak is doing fewer multiplies.  F(2,3) along the row axis:
+//
+//     out[y, 2t  ] = M0 + M1 + M2          M_v[y,t,o] = sum_{ky,ci} U_v[o][ky][ci] * V_v[y+ky-1, t, ci]
+//     out[y, 2t+1] = M1 - M2 - M3
+//     V0 = d0 - d2,  V1 = d1 + d2,  V2 = d2 - d1,  V3 = d1 - d3        d_j = x[., 2t-1+j, ci]   (zero / mirrored outside)
+//     U0 = w0,  U1 = (w0 + w1 + w2)/2,  U2 = (w0 - w1 + w2)/2,  U3 = w2  w_kx = w[o][ky][kx][ci]
+//
+// i.e. four GEMMs (v = 0..3) with M = B*H*W/2 "column pairs", N = Cout, K = 3*Cin: 6 multiplies per output instead
+// of 9 (1.5x fewer MFMAs), exact in exact arithmetic, f32 error of the same class as the direct kernel (the
+// transforms only add; the 1/2 in U is exact).  The input transform is two vector subtractions on the operand's way
+// into LDS, the output transform two adds in the epilogue on values a lane already holds (all four v of an output
+// element live in the same lane), so nothing extra touches HBM.
+//
+// Block = 256 threads = 4 waves, tile 128 column-pairs (256 output pixels) x 64 channels x K-step 8.  Wave w owns
+// rows [32w, 32w+32) x 64 channels x 4 v = 8 accumulators of 32x32.  LDS rows are 8 floats with an XOR slot swizzle
+// ((row>>3)&1) instead of padding -> conflict-free ds_read_b128, 48 KB double-buffered.  Same pipeline as
+// conv_igemm: one basic block per K-step, loads of step t+2 issued while step t computes.
+#include "common.hpp"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int WBM = 128;  // column pairs per block
+constexpr int WBN = 64;   // output channels per block
+constexpr int WBK = 8;    // K depth per step
+
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mulv4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 keepv4(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+__device__ __forceinline__ int wino_swizzle(int row, int slot) { return (slot ^ ((row >> 3) & 1)) * 4; }
+
+__device__ __forceinline__ int xcd_swz(int bid, int nblk) {
+    const int q = nblk >> 3, rem = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
+template <bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                              const float* __restrict__ umat,
+                                                              const float* __restrict__ in_scale,
+                                                              const float* __restrict__ out_scale,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ resid, ideas_conv_params p,
+                                                              int tiles_n) {
+    constexpr int A_FLOATS = 4 * WBM * WBK, B_FLOATS = 4 * WBN * WBK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+    float* As = smem;                  // [2][4][WBM][8]
+    float* Bs = smem + 2 * A_FLOATS;   // [2][4][WBN][8]
+
+    const int t = threadIdx.x;
+    const int H = p.IH, W = p.IW, W2 = W >> 1;
+    const int64_t M = (int64_t)p.B * H * W2;
+    const int K = 3 * p.Cin;
+    const int swz = xcd_swz(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int64_t m0 = (int64_t)tile_m * WBM;
+    const int n0 = tile_n * WBN;
+
+    // ---- A staging: thread = (row r, float4 slot kq) -----------------------------------------------
+    const int ar = t >> 1, akq = t & 1;
+    const int64_t am = m0 + ar;
+    const bool a_rowok = am < M;
+    int a_b, a_y, a_tx;
+    {
+        const int64_t mm = a_rowok ? am : 0;
+        a_tx = (int)(mm % W2);
+        const int64_t q = mm / W2;
+        a_y = (int)(q % H);
+        a_b = (int)(q / H);
+    }
+    const int64_t a_base = (int64_t)a_b * H * W * p.Cin;
+    int ax[4];
+    bool axok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ix = 2 * a_tx - 1 + j;
+        if (REFLECT) { ix = reflect_coord(ix, W); axok[j] = true; }
+        else { axok[j] = ix >= 0 && ix < W; }
+        ax[j] = axok[j] ? ix : 0;
+    }
+    int k_ky = 0, k_ci = akq * 4;   // walker of this thread's K column (Cin % 8 == 0: a step never straddles ky)
+    // ---- B staging: two (v, n, kq) items per thread ---------------------------------------------------
+    const float* b_ptr[2];
+    bool b_ok[2];
+    int b_dst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int item = t + 256 * j;
+        const int v = item >> 7, n = (item >> 1) & 63, kq = item & 1;
+        b_ok[j] = n0 + n < p.Cout;
+        b_ptr[j] = umat + ((int64_t)v * p.Cout + (b_ok[j] ? n0 + n : 0)) * K + kq * 4;
+        b_dst[j] = (v * WBN + n) * WBK + wino_swizzle(n, kq);
+    }
+
+    float4 rd[4], rs, rb[2];
+    bool okd[4], kval;
+    auto gload = [&](int kt) {
+        kval = k_ky < 3;
+        int iy = a_y + k_ky - 1;
+        bool rowok = a_rowok && kval;
+        if (REFLECT) iy = reflect_coord(iy, H);
+        else rowok = rowok && iy >= 0 && iy < H;
+        const int64_t rowoff = a_base + (int64_t)(rowok ? iy : 0) * W * p.Cin + k_ci;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            okd[j] = rowok && axok[j];
+            rd[j] = *reinterpret_cast<const float4*>(x + (okd[j] ? rowoff + (int64_t)ax[j] * p.Cin : 0));
+        }
+        if (SCALE) rs = *reinterpret_cast<const float4*>(in_scale + (int64_t)a_b * p.Cin + k_ci);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            rb[j] = *reinterpret_cast<const float4*>((b_ok[j] && kval) ? b_ptr[j] + (int64_t)kt * WBK : umat);
+        k_ci += WBK;
+        const bool wrap = k_ci >= p.Cin;
+        k_ci -= wrap ? p.Cin : 0;
+        k_ky += wrap ? 1 : 0;
+    };
+    // the predicate of the B rows for the tile held in rb (kval belongs to the same gload)
+    auto lstore = [&](int buf) {
+        float4 d0 = keepv4(okd[0], rd[0]), d1 = keepv4(okd[1], rd[1]), d2 = keepv4(okd[2], rd[2]), d3 = keepv4(okd[3], rd[3]);
+        float4 v0 = sub4(d0, d2), v1 = add4(d1, d2), v2 = sub4(d2, d1), v3 = sub4(d1, d3);
+        if (SCALE) { v0 = mulv4(v0, rs); v1 = mulv4(v1, rs); v2 = mulv4(v2, rs); v3 = mulv4(v3, rs); }
+        float* a = As + buf * A_FLOATS + ar * WBK + wino_swizzle(ar, akq);
+        *reinterpret_cast<float4*>(a + 0 * WBM * WBK) = v0;
+        *reinterpret_cast<float4*>(a + 1 * WBM * WBK) = v1;
+        *reinterpret_cast<float4*>(a + 2 * WBM * WBK) = v2;
+        *reinterpret_cast<float4*>(a + 3 * WBM * WBK) = v3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<float4*>(Bs + buf * B_FLOATS + b_dst[j]) = keepv4(b_ok[j] && kval, rb[j]);
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][b][r] = 0.f;
+
+    const int a_row = wave * 32 + li;
+    const int a_off = a_row * WBK + wino_swizzle(a_row, lh);
+    int b_off[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) b_off[b] = (b * 32 + li) * WBK + wino_swizzle(b * 32 + li, lh);
+
+    const int nk = K / WBK;
+    gload(0);
+    lstore(0);
+    gload(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        lstore(buf ^ 1);
+        gload(kt + 2);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 fa = *reinterpret_cast<const float4*>(As + buf * A_FLOATS + v * WBM * WBK + a_off);
+            float4 fb[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[b] = *reinterpret_cast<const float4*>(Bs + buf * B_FLOATS + v * WBN * WBK + b_off[b]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float av = kk == 0 ? fa.x : kk == 1 ? fa.y : kk == 2 ? fa.z : fa.w;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float bv = kk == 0 ? fb[b].x : kk == 1 ? fb[b].y : kk == 2 ? fb[b].z : fb[b].w;
+                    acc[v][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[v][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: inverse transform in registers, then the usual gain / demod / bias / act / residual --------
+    int64_t* row_off = reinterpret_cast<int64_t*>(smem);
+    int* row_b = reinterpret_cast<int*>(smem + 2 * WBM);
+    if (t < WBM) {
+        const int64_t m = m0 + t;
+        int64_t off = -1;
+        int b = 0;
+        if (m < M) {
+            const int tx = (int)(m % W2);
+            const int64_t q = m / W2;
+            const int yy = (int)(q % H);
+            b = (int)(q / H);
+            off = (((int64_t)b * H + yy) * W + 2 * tx) * p.Cout;
+        }
+        row_off[t] = off;
+        row_b[t] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + b * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bvv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int64_t off = row_off[row];
+            if (off < 0) continue;
+            const float m0v = acc[0][b][r], m1v = acc[1][b][r], m2v = acc[2][b][r], m3v = acc[3][b][r];
+            float o[2];
+            o[0] = (m0v + m1v) + m2v;
+            o[1] = (m1v - m2v) - m3v;
+            const float os = out_scale ? out_scale[(int64_t)row_b[row] * p.Cout + n] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float v = mul_rn(o[e], p.gain);
+                if (out_scale) v = mul_rn(v, os);
+                v = mul_then_add(v, 1.0f, bvv);
+                if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                const int64_t yi = off + (int64_t)e * p.Cout + n;
+                if (resid) v = (v + resid[yi]) * p.resid_gain;
+                if (p.accumulate) y[yi] += v; else y[yi] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// umat: [4][Cout][3][Cin] (v, o, ky, ci) transformed weights.  Geometry: x [B,H,W,Cin] -> y [B,H,W,Cout], 3x3,
+// stride 1, padding 1 (zero or mirrored); requires W even, Cin % 8 == 0.
+extern "C" int ideas_conv3x3_wino(void* y, const void* x, const void* umat, const float* in_scale, const float* out_scale,
+                                  const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
+                                  void* stream_) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!y || !x || !umat || !p) return IDEAS_E_NULL;
+    if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;
+    if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->OH != p->IH || p->OW != p->IW || p->YH != p->IH ||
+        p->YW != p->IW || p->osy != 1 || p->osx != 1 || p->ooy != 0 || p->oox != 0)
+        return IDEAS_E_UNSUPPORTED;
+    if ((p->IW & 1) || (p->Cin % 8)) return IDEAS_E_ALIGN;
+    if (p->reflect && (p->IH < 2 || p->IW < 2)) return IDEAS_E_SHAPE;
+    if (!ideas_aligned16(x) || !ideas_aligned16(umat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t M = (int64_t)p->B * p->IH * (p->IW / 2);
+    const int64_t tm = ideas_cdiv(M, WBM);
+    const int tn = (int)ideas_cdiv(p->Cout, WBN);
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv3x3_wino_kernel<decltype(sc)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
+                           dim3(256), 0, stream, (float*)y, (const float*)x, (const float*)umat, in_scale, out_scale, bias,
+                           (const float*)resid, *p, tn);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}

@@ -22,6 +22,31 @@ from .conv_plan import ConvGeom, Launch, convT_out_size, plan_dgrad, plan_fwd, p
 
 CL = torch.channels_last
 
+# 1-D Winograd F(2,3) for the 3x3 / stride-1 / pad-1 layers (csrc/conv_wino.hip): 1.5x fewer MFMAs.
+# IDEAS_WINOGRAD=0 falls back to the direct implicit GEMM (A/B measurements, debugging).
+import os as _os
+WINOGRAD = _os.environ.get("IDEAS_WINOGRAD", "1") != "0"
+
+
+def wino_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
+    """[O,3,3,I] (o, ky, kx, ci) -> U [4,O,3,I]: U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2 over kx."""
+    w0, w1, w2 = w_ohwi[:, :, 0], w_ohwi[:, :, 1], w_ohwi[:, :, 2]
+    s = w0 + w2
+    return torch.stack((w0, (s + w1) * 0.5, (s - w1) * 0.5, w2)).contiguous()
+
+
+def _wino_ok(g: "ConvGeom", cin: int, width: int) -> bool:
+    return WINOGRAD and g.kh == 3 and g.kw == 3 and g.stride == 1 and g.pad == 1 and width % 2 == 0 and cin % 8 == 0
+
+
+def launch_wino(y, x, umat, b, cin, h, w, cout, gain, reflect, in_scale=None, out_scale=None, bias=None, resid=None,
+                act=False, alpha=0.2, act_gain=1.0, resid_gain=1.0) -> None:
+    p = _lib.ConvParams(b, h, w, cin, h, w, cout, h, w, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(reflect), int(act),
+                        alpha, act_gain, resid_gain, 0, gain)
+    rc = _lib.load().ideas_conv3x3_wino(_lib.ptr(y), _lib.ptr(x), _lib.ptr(umat), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                        _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.F32, _lib.stream_ptr())
+    _lib.check(rc, "ideas_conv3x3_wino")
+
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
@@ -70,10 +95,17 @@ def launch_wgrad(gw: torch.Tensor, gy: torch.Tensor, x: torch.Tensor, L: Launch,
 def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None, act=False, act_gain=1.0,
                  resid=None, resid_gain=1.0, alpha=0.2):
     x = _nhwc(x)
-    L = plan_fwd(x.shape, w, g)
-    y = torch.empty((L.B, L.Cout, L.YH, L.YW), device=x.device, dtype=x.dtype, memory_format=CL)
     if resid is not None:
         resid = _nhwc(resid)
+    if _wino_ok(g, x.shape[1], x.shape[3]):
+        b, ci, h, wd = x.shape
+        co = w.shape[0]
+        y = torch.empty((b, co, h, wd), device=x.device, dtype=x.dtype, memory_format=CL)
+        launch_wino(y, x, wino_weights(w.permute(0, 2, 3, 1)), b, ci, h, wd, co, gain, g.reflect, lin, lout, bias, resid,
+                    act=act, alpha=alpha, act_gain=act_gain, resid_gain=resid_gain)
+        return y
+    L = plan_fwd(x.shape, w, g)
+    y = torch.empty((L.B, L.Cout, L.YH, L.YW), device=x.device, dtype=x.dtype, memory_format=CL)
     launch_fwd(y, x, L, gain, lin, lout, bias, resid, act=act, alpha=alpha, act_gain=act_gain, resid_gain=resid_gain)
     return y
 
@@ -88,6 +120,14 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
         gxp = conv_dgrad_raw(gy, w, gp, (ph, pw), gain, lin, lout)
         like = gxp.new_empty((gxp.shape[0], gxp.shape[1], in_hw[0], in_hw[1]))
         return torch.ops.aten.reflection_pad2d_backward(gxp.contiguous(), like, [g.pad] * 4)
+    if in_hw == (gy.shape[2], gy.shape[3]) and _wino_ok(g, gy.shape[1], gy.shape[3]):
+        # dgrad of a 3x3/s1/p1 conv = the same conv with the taps flipped and the channel roles swapped
+        b, co, h, wd = gy.shape
+        ci = w.shape[1]
+        gx = torch.empty((b, ci, h, wd), device=gy.device, dtype=gy.dtype, memory_format=CL)
+        u = wino_weights(w.flip(2, 3).permute(1, 2, 3, 0))       # [I, ky', kx', O]
+        launch_wino(gx, gy, u, b, co, h, wd, ci, gain, False, lin, lout)
+        return gx
     launches, need_zero = plan_dgrad(gy.shape, w, g, in_hw)
     b, ci = gy.shape[0], w.shape[1]
     gx = torch.empty((b, ci, in_hw[0], in_hw[1]), device=gy.device, dtype=gy.dtype, memory_format=CL)
