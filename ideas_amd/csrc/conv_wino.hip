@@ -231,6 +231,173 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(float* __restrict_
     }
 }
 
+// =====================================================================================================
+// weight gradient in the Winograd domain:
+//     dU_v[o][ky][ci] += gain * sum_{b,y,t} dM_v[b,y,t,o] * V_v[b, y+ky-1, t, ci]
+//     dM0 = g0, dM1 = g0 + g1, dM2 = g0 - g1, dM3 = -g1      g_e = gy[b, y, 2t+e, o]  (x out_scale)
+// (the host folds dU back to the 3x3 taps: dw0 = dU0 + (dU1+dU2)/2, dw1 = (dU1-dU2)/2, dw2 = (dU1+dU2)/2 + dU3).
+// Same structure as conv_wgrad_kernel (pixel-major LDS tiles, ds_read_b32 operands, split-K + atomics), with the
+// reduction running over column PAIRS and four accumulator sets; tile 64 (o) x 128 (ky,ci) x 8 pairs.
+// =====================================================================================================
+constexpr int GBM = 64, GBN = 128, GBK = 8;
+
+template <bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_wgrad_kernel(float* __restrict__ gu, const float* __restrict__ gy,
+                                                                    const float* __restrict__ x,
+                                                                    const float* __restrict__ in_scale,
+                                                                    const float* __restrict__ out_scale,
+                                                                    ideas_conv_params p, int tiles_n,
+                                                                    int64_t pairs_per_split) {
+    constexpr int LDM = GBM + 4, LDN = GBN + 4;
+    constexpr int G_FLOATS = 4 * GBK * LDM, X_FLOATS = 4 * GBK * LDN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (G_FLOATS + X_FLOATS)];
+    float* Gs = smem;                  // [2][4][GBK][LDM]
+    float* Xs = smem + 2 * G_FLOATS;   // [2][4][GBK][LDN]
+
+    const int t = threadIdx.x;
+    const int H = p.IH, W = p.IW, W2 = W >> 1;
+    const int Ktot = 3 * p.Cin;
+    const int64_t P2 = (int64_t)p.B * H * W2;
+    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    const int o0 = tile_m * GBM, n0 = tile_n * GBN;
+    const int64_t pbeg = (int64_t)blockIdx.y * pairs_per_split;
+    const int64_t pend = (pbeg + pairs_per_split < P2) ? pbeg + pairs_per_split : P2;
+    if (pbeg >= pend) return;
+
+    struct Walk { int b, y, tx, left; };
+    auto walk_init = [&](int pr) {
+        Walk wk;
+        const int64_t pp = pbeg + pr;
+        wk.left = (int)(pend - pp);
+        const int64_t q = pp / W2;
+        wk.tx = (int)(pp - q * W2);
+        wk.b = (int)(q / H);
+        wk.y = (int)(q - (int64_t)wk.b * H);
+        return wk;
+    };
+    auto walk_step = [&](Walk& wk) {
+        wk.left -= GBK;
+        wk.tx += GBK;
+        while (wk.tx >= W2) {
+            wk.tx -= W2;
+            if (++wk.y == H) { wk.y = 0; ++wk.b; }
+        }
+    };
+    // G items: threads 0..127 -> (pair row pr = t/16, channel quad oq = t%16)
+    const bool g_active = t < GBK * (GBM / 4);
+    const int g_pr = (t >> 4) & (GBK - 1), g_oq = t & 15;
+    const int g_o = o0 + g_oq * 4;
+    const bool g_ok = g_active && g_o < p.Cout;
+    Walk gwk = walk_init(g_pr);
+    // X items: every thread -> (pair row pr = t/32, k quad kq = t%32)
+    const int x_pr = t >> 5, x_kq = t & 31;
+    const int x_k = n0 + x_kq * 4;
+    const bool x_ok = x_k < Ktot;
+    const int x_ky = (x_ok ? x_k : 0) / p.Cin;
+    const int x_ci = (x_ok ? x_k : 0) - x_ky * p.Cin;
+    Walk xwk = walk_init(x_pr);
+
+    float4 rg[2], rgs, rx[4], rxs;
+    bool okg, okx[4];
+    auto gload = [&]() {
+        {
+            const Walk wk = gwk;
+            okg = g_ok && wk.left > 0;
+            const int64_t off = okg ? (((int64_t)wk.b * H + wk.y) * W + 2 * wk.tx) * p.Cout + g_o : 0;
+            rg[0] = *reinterpret_cast<const float4*>(gy + off);
+            rg[1] = *reinterpret_cast<const float4*>(gy + off + (okg ? p.Cout : 0));
+            if (SCALE) rgs = *reinterpret_cast<const float4*>(out_scale + (okg ? (int64_t)wk.b * p.Cout + g_o : 0));
+            walk_step(gwk);
+        }
+        {
+            const Walk wk = xwk;
+            int iy = wk.y + x_ky - 1;
+            bool rowok = x_ok && wk.left > 0;
+            if (REFLECT) iy = reflect_coord(iy, H);
+            else rowok = rowok && iy >= 0 && iy < H;
+            const int64_t rowoff = ((int64_t)wk.b * H + (rowok ? iy : 0)) * W * p.Cin + x_ci;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int ix = 2 * wk.tx - 1 + j;
+                bool ok = rowok;
+                if (REFLECT) ix = reflect_coord(ix, W);
+                else ok = ok && ix >= 0 && ix < W;
+                okx[j] = ok;
+                rx[j] = *reinterpret_cast<const float4*>(x + (ok ? rowoff + (int64_t)ix * p.Cin : 0));
+            }
+            if (SCALE) rxs = *reinterpret_cast<const float4*>(in_scale + (rowok ? (int64_t)wk.b * p.Cin + x_ci : 0));
+            walk_step(xwk);
+        }
+    };
+    auto lstore = [&](int buf) {
+        if (g_active) {
+            float4 g0 = keepv4(okg, rg[0]), g1 = keepv4(okg, rg[1]);
+            if (SCALE) { g0 = mulv4(g0, rgs); g1 = mulv4(g1, rgs); }
+            float* dst = Gs + buf * G_FLOATS + g_pr * LDM + g_oq * 4;
+            *reinterpret_cast<float4*>(dst + 0 * GBK * LDM) = g0;
+            *reinterpret_cast<float4*>(dst + 1 * GBK * LDM) = add4(g0, g1);
+            *reinterpret_cast<float4*>(dst + 2 * GBK * LDM) = sub4(g0, g1);
+            *reinterpret_cast<float4*>(dst + 3 * GBK * LDM) = make_float4(-g1.x, -g1.y, -g1.z, -g1.w);
+        }
+        float4 d0 = keepv4(okx[0], rx[0]), d1 = keepv4(okx[1], rx[1]), d2 = keepv4(okx[2], rx[2]), d3 = keepv4(okx[3], rx[3]);
+        float4 v0 = sub4(d0, d2), v1 = add4(d1, d2), v2 = sub4(d2, d1), v3 = sub4(d1, d3);
+        if (SCALE) { v0 = mulv4(v0, rxs); v1 = mulv4(v1, rxs); v2 = mulv4(v2, rxs); v3 = mulv4(v3, rxs); }
+        float* dst = Xs + buf * X_FLOATS + x_pr * LDN + x_kq * 4;
+        *reinterpret_cast<float4*>(dst + 0 * GBK * LDN) = v0;
+        *reinterpret_cast<float4*>(dst + 1 * GBK * LDN) = v1;
+        *reinterpret_cast<float4*>(dst + 2 * GBK * LDN) = v2;
+        *reinterpret_cast<float4*>(dst + 3 * GBK * LDN) = v3;
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;     // 2 x 2 waves: 32 (o) x 64 (k) each
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[v][b][r] = 0.f;
+
+    const int64_t nsteps = (pend - pbeg + GBK - 1) / GBK;
+    gload();
+    lstore(0);
+    gload();
+    __syncthreads();
+    for (int64_t s = 0; s < nsteps; ++s) {
+        const int buf = (int)(s & 1);
+        lstore(buf ^ 1);
+        gload();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int prow = lh * 4 + kk;
+                const float av = Gs[buf * G_FLOATS + (v * GBK + prow) * LDM + wm * 32 + li];
+                float bv[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bv[b] = Xs[buf * X_FLOATS + (v * GBK + prow) * LDN + (wn * 2 + b) * 32 + li];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[v][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[b], acc[v][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int k = n0 + (wn * 2 + b) * 32 + li;
+            if (k >= Ktot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < p.Cout) atomicAdd(&gu[((int64_t)v * p.Cout + o) * Ktot + k], acc[v][b][r] * p.gain);
+            }
+        }
+}
+
 }  // namespace
 
 // umat: [4][Cout][3][Cin] (v, o, ky, ci) transformed weights.  Geometry: x [B,H,W,Cin] -> y [B,H,W,Cout], 3x3,
@@ -256,6 +423,59 @@ extern "C" int ideas_conv3x3_wino(void* y, const void* x, const void* umat, cons
         hipLaunchKernelGGL((conv3x3_wino_kernel<decltype(sc)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
                            dim3(256), 0, stream, (float*)y, (const float*)x, (const float*)umat, in_scale, out_scale, bias,
                            (const float*)resid, *p, tn);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
+// gu: ZEROED [4][Cout][3][Cin]; gy [B,H,W,Cout], x [B,H,W,Cin].  Same geometry restrictions as ideas_conv3x3_wino,
+// plus Cout % 4 == 0.  in_scale / out_scale: both or neither.
+extern "C" int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale,
+                                        const float* out_scale, const ideas_conv_params* p, int dtype, void* stream_) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!gu || !gy || !x || !p) return IDEAS_E_NULL;
+    if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;
+    if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->OH != p->IH || p->OW != p->IW || p->YH != p->IH ||
+        p->YW != p->IW)
+        return IDEAS_E_UNSUPPORTED;
+    if ((p->IW & 1) || (p->Cin % 8) || (p->Cout % 4)) return IDEAS_E_ALIGN;
+    if ((in_scale == nullptr) != (out_scale == nullptr)) return IDEAS_E_UNSUPPORTED;
+    if (!ideas_aligned16(x) || !ideas_aligned16(gy) || (in_scale && (!ideas_aligned16(in_scale) || !ideas_aligned16(out_scale))))
+        return IDEAS_E_ALIGN;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t P2 = (int64_t)p->B * p->IH * (p->IW / 2);
+    if (P2 >= 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const int Ktot = 3 * p->Cin;
+    const int tm = (int)ideas_cdiv(p->Cout, GBM), tn = (int)ideas_cdiv(Ktot, GBN);
+    const int64_t tiles = (int64_t)tm * tn;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int64_t slots = 2LL * n_cu;                       // 2 blocks per CU (208 VGPRs)
+    const int64_t max_splits = ideas_cdiv(P2, 16 * GBK);
+    int64_t splits = (2 * slots) / tiles;
+    if (splits < 1) splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 65535) splits = 65535;
+    int64_t per = ideas_cdiv(ideas_cdiv(P2, splits), GBK) * GBK;
+    splits = ideas_cdiv(P2, per);
+    {
+        const int64_t blocks = tiles * splits, waves = blocks / slots;
+        if (waves >= 1 && blocks % slots) {
+            const int64_t want = (waves * slots) / tiles;
+            if (want >= 1) { per = ideas_cdiv(ideas_cdiv(P2, want), GBK) * GBK; splits = ideas_cdiv(P2, per); }
+        }
+    }
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<decltype(sc)::value, decltype(rf)::value>),
+                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gu, (const float*)gy,
+                           (const float*)x, in_scale, out_scale, *p, tn, per);
     };
     using T = std::true_type;
     using F = std::false_type;

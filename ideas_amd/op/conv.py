@@ -141,6 +141,23 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
 def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None):
     """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy."""
     gy, x = _nhwc(gy), _nhwc(x)
+    if (lin is None) != (lout is None):   # the MFMA wgrad kernels take both per-sample scales or neither
+        if lin is None:
+            lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
+        else:
+            lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
+    if _wino_ok(g, x.shape[1], x.shape[3]) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
+        b, ci, h, wd = x.shape
+        co = gy.shape[1]
+        gu = torch.zeros((4, co, 3, ci), device=x.device, dtype=torch.float32)
+        p = _lib.ConvParams(b, h, wd, ci, h, wd, co, h, wd, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(g.reflect), 0, 0.2,
+                            1.0, 1.0, 0, gain)
+        rc = _lib.load().ideas_conv3x3_wino_wgrad(_lib.ptr(gu), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(lin), _lib.ptr(lout),
+                                                  C.byref(p), _lib.F32, _lib.stream_ptr())
+        _lib.check(rc, "ideas_conv3x3_wino_wgrad")
+        half = (gu[1] + gu[2]) * 0.5
+        dw = torch.stack((gu[0] + half, (gu[1] - gu[2]) * 0.5, half + gu[3]), dim=2)    # [O, ky, kx, I]
+        return dw.permute(0, 3, 1, 2)                                                  # [O, I, 3, 3], OHWI in memory
     L = plan_wgrad(x.shape, gy.shape, g)
     if (lin is None) != (lout is None):   # the MFMA wgrad kernel takes both per-sample scales or neither
         if lin is None:

@@ -134,6 +134,12 @@ int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_s
 int ideas_conv3x3_wino(void* y, const void* x, const void* umat, const float* in_scale, const float* out_scale,
                        const float* bias, const void* resid, const ideas_conv_params* p, int dtype, void* stream);
 
+/* Weight gradient of the same layers in the Winograd domain: gu (ZEROED float [4][Cout][3][Cin]) receives
+ * dU_v = gain * sum dM_v (x) V_v with dM = (g0, g0+g1, g0-g1, -g1); the caller folds it back to the 3x3 taps:
+ * dw[kx=0] = dU0 + (dU1+dU2)/2, dw[kx=1] = (dU1-dU2)/2, dw[kx=2] = (dU1+dU2)/2 + dU3.  Cout % 4 == 0 as well. */
+int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                             const ideas_conv_params* p, int dtype, void* stream);
+
 /* Generic direct convolution (VALU) with the same parameterisation and epilogue; any Cin/Cout. Used for the
  * handful of tiny-K layers (RGB / N-channel inputs) where the MFMA tile would be empty. */
 int ideas_conv_direct(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
