@@ -194,3 +194,31 @@ def check_replay(g, meta, trainer, out, log):
 def test_step_replay_gpu(which):
     g, meta, trainer, out, log = replay_step(which, "cuda")
     check_replay(g, meta, trainer, out, log)
+
+
+def test_extraction_block_bit_decisions_match_oracle():
+    """Sender/receiver block of train.py:249-286 (bits -> Z -> Gstru -> G -> E -> Ex -> bits) on the GPU nets vs the
+    CPU oracle on identical weights: same hat_Z to tolerance and bit-identical decisions; N=1 and N=2."""
+    import oracle.torch_ref as O
+    from ideas_amd import train_step as TS
+    from ideas_amd.models import init_model
+    for N in (1, 2):
+        args = TS.default_args(channel=8, texture_channel=128, channel_multiplier=0.25, image_size=64, N=N, use_dco=False)
+        torch.manual_seed(40 + N)
+        tr = TS.build_trainer(args, "cpu", init_model)
+        B = 3
+        X = torch.rand(B, 3, 64, 64) * 2 - 1
+        M = torch.randint(0, 2, (B, N * 16), dtype=torch.float)
+        jitter = torch.rand(B, N * 16)
+        T2 = torch.rand(B, 128) * 2 - 1
+        cfg = O.Cfg(channel=8, structure_channel=8, texture_channel=128, N=N, image_size=64, channel_multiplier=0.25)
+        P = {n: {k: v.detach().clone().contiguous() for k, v in tr[n + "_ema"].state_dict().items()} for n in ("E", "G", "Gstru", "Ex")}
+        for use_x3 in (False, True):
+            rz, rm, racc, _ = O.extraction_test(P, cfg, X, M, jitter, T2, use_x3)
+            for v in tr.values():
+                if isinstance(v, torch.nn.Module):
+                    v.cuda()
+            hz, hm, acc, _ = TS.extraction_test(tr, args, X.cuda(), M.cuda(), T2.cuda(), use_x3, jitter=jitter.cuda())
+            assert rel_err(hz, rz) < 2e-5
+            assert torch.equal(hm.cpu(), rm), "secret-bit decisions differ"
+            assert abs(float(acc) - float(racc)) < 1e-7

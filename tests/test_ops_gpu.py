@@ -332,3 +332,119 @@ def test_modconv_act_fused_vs_oracle(ops, case):
                               dev(gy.float(), True))
     for a, c, n in zip(got, ref, ("gx", "gstyle", "gw", "gmw", "gmb", "gbias")):
         assert rel_err(a, c) < GTOL, (n, case, rel_err(a, c))
+
+
+# --------------------------------------------------------------------------------------------- Winograd F(2,3)
+WINO_CASES = [
+    # B, Cin, Cout, H, W, reflect, scaled
+    (2, 8, 16, 6, 8, False, False), (2, 16, 64, 16, 16, False, False), (3, 32, 100, 9, 14, False, False),
+    (2, 64, 130, 17, 32, False, True), (2, 32, 64, 16, 16, True, False), (1, 128, 128, 8, 2, False, True),
+    (2, 24, 40, 5, 2, True, False), (2, 512, 64, 4, 4, False, False),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_kernels_vs_direct_and_oracle(case):
+    """conv_wino.hip (forward, input-gradient and Winograd-domain weight-gradient) against the f64 oracle and
+    against the direct implicit GEMM on the same inputs (IDEAS_WINOGRAD toggles the dispatch)."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, refl, scaled = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    w = torch.randn(co, ci, 3, 3, dtype=torch.float64)
+    s = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if scaled else None
+    d = (torch.rand(B, co, dtype=torch.float64) + 0.5) if scaled else None
+    xs = x * s.view(B, ci, 1, 1) if scaled else x
+    xin = F.pad(xs, [1] * 4, mode="reflect") if refl else xs
+    y = F.conv2d(xin, w * 0.1, padding=0 if refl else 1)
+    if scaled:
+        y = y * d.view(B, co, 1, 1)
+    gy = torch.randn_like(y)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xs_r = xr * s.view(B, ci, 1, 1) if scaled else xr
+    yr = F.conv2d(F.pad(xs_r, [1] * 4, mode="reflect") if refl else xs_r, wr * 0.1, padding=0 if refl else 1)
+    if scaled:
+        yr = yr * d.view(B, co, 1, 1)
+    gx_ref, gw_ref = torch.autograd.grad(yr, (xr, wr), gy)
+    g = ConvGeom(3, 3, 1, 1, refl)
+    xd, wd, gyd = dev(x.float(), True), dev(w.float(), True), dev(gy.float(), True)
+    sd = dev(s.float()) if scaled else None
+    dd = dev(d.float()) if scaled else None
+    res = {}
+    for flag in (True, False):
+        CV.WINOGRAD = flag
+        try:
+            yy = CV.conv_fwd_raw(xd, wd, g, 0.1, lin=sd, lout=dd)
+            gw = CV.conv_wgrad_raw(gyd, xd, g, tuple(w.shape), 0.1, lin=sd, lout=dd)
+            gx = None if refl else CV.conv_dgrad_raw(gyd, wd, g, (H, W), 0.1, lin=dd, lout=sd)
+        finally:
+            CV.WINOGRAD = True
+        res[flag] = (yy, gw, gx)
+        assert rel_err(yy, y) < TOL, ("y", flag, case, rel_err(yy, y))
+        assert rel_err(gw, gw_ref) < GTOL, ("gw", flag, case, rel_err(gw, gw_ref))
+        if gx is not None:
+            assert rel_err(gx, gx_ref) < GTOL, ("gx", flag, case, rel_err(gx, gx_ref))
+    # the two kernel families agree with each other to f32 round-off
+    assert rel_err(res[True][0], res[False][0]) < 5e-6
+
+
+def test_winograd_full_size_properties():
+    """BASELINE-size check (G.layers.7.conv2: 128->128 @256x256, B=8) through size-independent properties:
+    linearity in the input, agreement with the direct kernel, and <gy, conv(x)> == <dgrad(gy), x> (adjointness)."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    torch.manual_seed(0)
+    B, C, R = 8, 128, 256
+    g = ConvGeom(3, 3, 1, 1, False)
+    x1 = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL)
+    x2 = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL)
+    w = torch.randn(C, C, 3, 3, device="cuda").contiguous(memory_format=CL)
+    gain = 1 / math.sqrt(C * 9)
+    y1, y2 = CV.conv_fwd_raw(x1, w, g, gain), CV.conv_fwd_raw(x2, w, g, gain)
+    y12 = CV.conv_fwd_raw(x1 + 2 * x2, w, g, gain)
+    assert rel_err(y12, y1 + 2 * y2) < 5e-6
+    CV.WINOGRAD = False
+    try:
+        yd = CV.conv_fwd_raw(x1, w, g, gain)
+    finally:
+        CV.WINOGRAD = True
+    assert rel_err(y1, yd) < 5e-6
+    gy = torch.randn_like(y1)
+    gx = CV.conv_dgrad_raw(gy, w, g, (R, R), gain)
+    lhs = float((gy.double() * y1.double()).sum())
+    rhs = float((gx.double() * x1.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
+    gw = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)
+    lhs_w = float((gw.double() * w.double()).sum())       # <dL/dw, w> == <gy, conv(x, w)> for a conv linear in w
+    assert abs(lhs_w - lhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
+
+
+# --------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_blur_and_bias_act_properties():
+    """BASELINE sizes (B=32, 128 ch, 256x256): properties that need no reference at that size.
+    blur: linearity, <blur(x), g> == <x, blur^T(g)> (autograd adjoint), DC gain 1 in the interior;
+    bias_act: backward mask consistent with forward sign, bias-gradient == plain sum of the input gradient."""
+    import ideas_amd.op as op
+    from ideas_amd.model import make_kernel
+    torch.manual_seed(1)
+    B, C, R = 32, 128, 256
+    k = make_kernel((1, 3, 3, 1)).cuda()
+    x = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL).requires_grad_(True)
+    y = op.upfirdn2d(x, k, pad=(2, 2))
+    assert tuple(y.shape) == (B, C, R + 1, R + 1)
+    g = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, g)
+    lhs, rhs = float((y.double() * g.double()).sum()), float((gx.double() * x.detach().double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs) + 1e-2
+    ones = torch.ones(1, 4, 64, 64, device="cuda").contiguous(memory_format=CL)
+    assert torch.allclose(op.upfirdn2d(ones, k, pad=(2, 2))[:, :, 3:-3, 3:-3], torch.ones(1, 4, 59, 59, device="cuda"), atol=1e-6)
+    b = torch.randn(C, device="cuda").requires_grad_(True)
+    xa = x.detach().requires_grad_(True)
+    out = op.fused_leaky_relu(xa, b)
+    assert torch.equal(out > 0, (xa.detach() + b.detach().view(1, -1, 1, 1)) > 0)
+    gxa, gb = torch.autograd.grad(out, (xa, b), torch.ones_like(out))
+    # f64 reference; 2M same-sign addends per channel are the worst case for the f32 block-partial + atomic tree
+    assert rel_err(gb, gxa.double().sum(dim=(0, 2, 3))) < 5e-5
+    pos = out.detach() > 0
+    assert torch.allclose(gxa[pos], torch.full_like(gxa[pos], 2 ** 0.5)) and torch.allclose(gxa[~pos], torch.full_like(gxa[~pos], 0.2 * 2 ** 0.5))
