@@ -159,10 +159,17 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # IDEAS_BENCH_SHARE_GPU=1 (+ IDEAS_DIST_BACKEND=gloo) lets the multi-rank code path be exercised on a 1-GPU box
+    if os.environ.get("IDEAS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        backend = os.environ.get("IDEAS_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
 
     from ideas_amd import _lib, train_step as TS
     from ideas_amd.models import init_model

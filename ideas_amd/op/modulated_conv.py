@@ -157,6 +157,45 @@ class _ModConvAct(Function):
         return (gx if need_x else None), gw, gs, gd, (gb if need_b else None), None, None, None
 
 
+_SECOND_ORDER = [False]
+
+
+class second_order:
+    """Context manager: build the modulated conv from individually double-differentiable ops
+    (x*s -> conv2d / conv_transpose2d -> *d, demodulation in plain torch) so that
+    ``autograd.grad(..., create_graph=True)`` w.r.t. the style works — what the path-length regulariser
+    (stylegan2/train.py:85-98) needs.  Two extra elementwise passes; used only on those regularisation steps."""
+
+    def __enter__(self):
+        self.prev = _SECOND_ORDER[0]
+        _SECOND_ORDER[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _SECOND_ORDER[0] = self.prev
+
+
+def _modulated_conv2d_composite(x, w, style, demodulate, upsample, fir, eps, act_bias, negative_slope, act_scale):
+    from .conv import conv2d, conv_transpose2d
+    cout, cin, k, _ = w.shape
+    scale = 1.0 / math.sqrt(cin * k * k)
+    xs = x * style.view(style.shape[0], cin, 1, 1)
+    if upsample:
+        y = conv_transpose2d(xs, w.transpose(0, 1), None, stride=2, gain=scale)
+    else:
+        y = conv2d(xs, w, None, stride=1, padding=k // 2, gain=scale)
+    if demodulate:
+        wsq = (w * w).sum(dim=(2, 3)) * (scale * scale)
+        d = torch.rsqrt((style * style) @ wsq.t() + eps)
+        y = y * d.view(d.shape[0], cout, 1, 1)
+    if upsample:
+        p = (fir.shape[0] - 2) - (k - 1)
+        y = upfirdn2d(y, fir, pad=((p + 1) // 2 + 1, p // 2 + 1))
+    if act_bias is not None:
+        y = fused_leaky_relu(y, act_bias, negative_slope, act_scale)
+    return y
+
+
 def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor, demodulate: bool = True,
                      upsample: bool = False, fir: Optional[torch.Tensor] = None, eps: float = 1e-8,
                      act_bias: Optional[torch.Tensor] = None, negative_slope: float = 0.2,
@@ -168,6 +207,8 @@ def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
     _lib.require_cuda(x, weight, style)
     w = weight[0] if weight.dim() == 5 else weight
     cout, cin, k, _ = w.shape
+    if _SECOND_ORDER[0] and torch.is_grad_enabled() and resid is None:
+        return _modulated_conv2d_composite(x, w, style, demodulate, upsample, fir, eps, act_bias, negative_slope, act_scale)
     scale = 1.0 / math.sqrt(cin * k * k)
     d = None
     if demodulate:

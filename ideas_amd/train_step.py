@@ -44,7 +44,9 @@ def default_args(**over) -> argparse.Namespace:
     a = argparse.Namespace(N=1, lambda_Ex=10.0, lr=0.002, batch_size=1, image_size=256, real_r1=10.0, texture_r1=1.0,
                            dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=16, channel=32, channel_multiplier=1,
                            structure_channel=8, texture_channel=2048, num_iters=100000, start_iter=0,
-                           blur_kernel=(1, 3, 3, 1), use_dco=True, elide_second_backward=True)
+                           blur_kernel=(1, 3, 3, 1), use_dco=True, elide_second_backward=True,
+                           # path-length regulariser of the vendored trainer (stylegan2/train.py:85-98,247-270): off in IDEAS
+                           path_regularize=0.0, g_reg_every=4, path_batch_shrink=2)
     a.__dict__.update(over)
     return a
 
@@ -229,14 +231,27 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         _sync("ex", ex_params)
         T["ex_optim"].step()
     else:
-        T["g_optim"].zero_grad(set_to_none=False)
-        loss_total.backward(retain_graph=True)
+        # The reference's literal schedule (train.py:209-216): Loss_total.backward(retain_graph) -> g step ->
+        # Loss_Ex.backward() (a second traversal of Ex -> E -> G -> Gstru) -> ex step.  Its second traversal reads the
+        # weights saved by the forward, i.e. the PRE-step values, so running it before the g step gives the same Ex
+        # gradient; that order is required here because these ops save the parameters themselves (the equalised-lr
+        # scale lives in the kernel), which the in-place Adam update would otherwise invalidate.
+        T["g_optim"].zero_grad(set_to_none=True)
+        T["ex_optim"].zero_grad(set_to_none=True)
+        losses["Ex_loss"].backward(retain_graph=True)
+        ex_grads = [None if p.grad is None else p.grad.detach().clone() for p in ex_params]
+        T["g_optim"].zero_grad(set_to_none=True)
+        T["ex_optim"].zero_grad(set_to_none=True)
+        loss_total.backward()
         _sync("g", g_params)
         T["g_optim"].step()
-        T["ex_optim"].zero_grad(set_to_none=False)
-        losses["Ex_loss"].backward()
+        _set_grads(ex_params, ex_grads)
         _sync("ex", ex_params)
         T["ex_optim"].step()
+
+    # ------------------------------------------------------------------ optional lazy path-length reg (not in IDEAS)
+    if args.path_regularize and iter_idx % args.g_reg_every == 0:
+        losses.update(path_length_step(T, args, X.shape[0], X.shape[-1], X.device, reducer=reducer))
 
     # ------------------------------------------------------------------ EMA (train.py:218-221)
     accum = 0.5 ** (32 / (10 * 1000))
@@ -244,6 +259,59 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         if n + "_ema" in T:
             accumulate(T[n + "_ema"], T[n], accum)
     return losses
+
+
+def g_path_regularize(fake_img: torch.Tensor, latents: torch.Tensor, mean_path_length, decay: float = 0.01,
+                      noise: Optional[torch.Tensor] = None):
+    """Path-length penalty (stylegan2/train.py:85-98) with ``latents`` = the texture code T [B, C]."""
+    import math
+    if noise is None:
+        noise = torch.randn_like(fake_img)
+    noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
+    (grad,) = torch.autograd.grad(outputs=(fake_img * noise).sum(), inputs=latents, create_graph=True)
+    path_lengths = torch.sqrt(grad.pow(2).sum(1))
+    path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
+    path_penalty = (path_lengths - path_mean).pow(2).mean()
+    return path_penalty, path_mean.detach(), path_lengths
+
+
+def path_length_step(trainer, args, batch: int, image_size: int, device, Z: Optional[torch.Tensor] = None,
+                     T: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, reducer=None):
+    """Lazy path-length regularisation of G (stylegan2/train.py:247-270): half batch, weight
+    ``path_regularize * g_reg_every``, generator step only.  The modulated convs run in their double-differentiable
+    composite form for this pass (ideas_amd.op.modulated_conv.second_order)."""
+    from .op.modulated_conv import second_order
+    T_ = trainer
+    pb = max(1, batch // args.path_batch_shrink)
+    s = image_size // 16
+    if Z is None:
+        Z = (torch.rand(size=(pb, args.N, s, s), dtype=torch.float) * 2 - 1).to(device)
+    if T is None:
+        T = torch.rand((pb, args.texture_channel), device=device) * 2 - 1
+    T = T.detach().requires_grad_(True)
+    with torch.no_grad():
+        S2 = T_["Gstru"](Z)
+    g_params = [p for p in T_["G"].parameters()]
+    with second_order():
+        fake = T_["G"](S2, T)
+        mean = trainer.get("mean_path_length", torch.zeros((), device=device))
+        penalty, mean_new, lengths = g_path_regularize(fake, T, mean, noise=noise)
+        weighted = args.path_regularize * args.g_reg_every * penalty
+        if args.path_batch_shrink:
+            weighted = weighted + 0 * fake[0, 0, 0, 0]
+        grads = torch.autograd.grad(weighted, g_params, allow_unused=True)
+    trainer["mean_path_length"] = mean_new
+    all_g = _params_of(T_, G_SIDE)
+    for p in all_g:
+        p.grad = None
+    _set_grads(g_params, grads)
+    if reducer is not None:
+        for p in all_g:                      # the flat bucket expects every parameter of the group
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        reducer("g", all_g)
+    T_["g_optim"].step()
+    return {"path_loss": penalty.detach(), "path_length": lengths.mean().detach()}
 
 
 @torch.no_grad()

@@ -513,6 +513,18 @@ def g_phase(nets, cfg: Cfg, args: StepArgs, X: Tensor, draws: StepDraws, iter_id
     return total, L["Ex_loss"], L, hat_Z
 
 
+def g_path_regularize(fake_img: Tensor, latents: Tensor, mean_path_length, decay: float = 0.01, noise: Optional[Tensor] = None):
+    """stylegan2/train.py:85-98 with latents = T [B, C] (the reference's own train.py has no
+    path-length term; this restates the vendored trainer's function for the build-side flag)."""
+    if noise is None:
+        noise = torch.randn_like(fake_img)
+    noise = noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3])
+    (grad,) = torch.autograd.grad((fake_img * noise).sum(), latents, create_graph=True)
+    path_lengths = torch.sqrt(grad.pow(2).sum(1))
+    path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
+    return (path_lengths - path_mean).pow(2).mean(), path_mean.detach(), path_lengths
+
+
 def extraction_test(nets, cfg: Cfg, X: Tensor, M: Tensor, jitter: Tensor, T2: Tensor, use_x3: bool):
     """train.py:249-286 with the EMA (or any) parameter sets.  Returns (hat_Z, hat_M, ACC, L1)."""
     with torch.no_grad():
