@@ -58,10 +58,12 @@ def parse():
 
 
 def roofline_probe(device, batch: int, launches: int):
-    """Dominant kernel = the f32-MFMA implicit GEMM (conv_igemm_kernel<2,2,2,2>) on its heaviest instance,
-    G.layers.7.conv2: modulated 3x3, 128 -> 128 channels at 256x256 (19.33 GFLOP per sample).
-    Timed with HIP events on the launch stream over `launches` back-to-back launches."""
-    from ideas_amd.op.conv import conv_fwd_raw
+    """Dominant kernel on its heaviest instance, G.layers.7.conv2: modulated 3x3, 128 -> 128 channels at 256x256
+    (19.33 GFLOP per sample).  With the default dispatch that is conv3x3_wino_kernel<true,false>
+    (1-D Winograd F(2,3): it executes 2/3 of the algorithmic multiplies on the f32 MFMA pipe); with IDEAS_WINOGRAD=0 it is
+    the direct implicit GEMM conv_igemm_kernel<2,2,2,2,true,false,true>.  `achieved` = ALGORITHMIC FLOPs / time, timed
+    with HIP events on the launch stream over `launches` back-to-back launches."""
+    from ideas_amd.op import conv as CV
     from ideas_amd.op.conv_plan import ConvGeom
     g = torch.Generator(device="cpu").manual_seed(7)
     x = torch.randn(batch, 128, 256, 256, generator=g).to(device).contiguous(memory_format=torch.channels_last)
@@ -70,21 +72,25 @@ def roofline_probe(device, batch: int, launches: int):
     d = (torch.rand(batch, 128, generator=g) + 0.5).to(device)
     geom = ConvGeom(3, 3, 1, 1, False)
     for _ in range(3):
-        conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
+        CV.conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(launches):
-        conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
+        CV.conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / launches
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
+    wino = CV.WINOGRAD
+    kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino
+              else "conv_igemm_kernel<2,2,2,2,true,false,true> (direct implicit GEMM)")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "conv_igemm_kernel<2,2,2,2> (G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d)" % batch,
-            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+            "kernel": kernel + " on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch,
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "mfma_executed_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
 def _cpu_baseline_worker(R: int, threads: int):
