@@ -156,3 +156,36 @@ def test_flop_table_matches_reference_hooks():
     for tag, cls in NET_CLASSES.items():
         gf = forward_flops(init_model(cls, a), 256) / 1e9
         assert abs(gf - ref[tag]) <= 0.01 * ref[tag], (tag, gf, ref[tag])
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """ideas_amd.checkpoint writes/reads the reference's .pt layout (train.py:308-322, 435-442): all 11 nets + 3
+    optimisers, iter_idx, N, args; a state-dict produced by the reference's key set loads strictly."""
+    from ideas_amd import checkpoint as CK, train_step as TS
+    from ideas_amd.models import init_model
+    args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=64)
+    torch.manual_seed(1)
+    tr = TS.build_trainer(args, "cpu", init_model)
+    # give the optimisers some state
+    for name in ("g_optim", "ex_optim", "d_optim"):
+        for grp in tr[name].param_groups:
+            for p in grp["params"]:
+                p.grad = torch.randn_like(p) * 1e-3
+        tr[name].step()
+    path = str(tmp_path / "7.pt")
+    CK.save(path, tr, args, 7)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(raw) == {"iter_idx", "N", "trainer", "args"} and raw["iter_idx"] == 7 and raw["N"] == args.N
+    assert set(raw["trainer"]) == set(CK.TRAINER_KEYS)
+    gold = json.load(open(os.path.join(GOLDEN, "init_checksums.json")))
+    assert list(raw["trainer"]["G"].keys()) == [k for k, _ in gold["G"]["keys"]]      # the reference's key names/order
+    torch.manual_seed(2)
+    tr2 = TS.build_trainer(args, "cpu", init_model)
+    assert CK.load(path, tr2) == 7
+    for name in ("E", "G", "Gstru", "Ex", "Dreal", "Dco", "Ddist", "G_ema"):
+        for (k1, v1), (k2, v2) in zip(tr[name].state_dict().items(), tr2[name].state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2)
+        assert all(p.is_contiguous(memory_format=torch.channels_last) for p in tr2[name].parameters() if p.dim() == 4)
+    s1, s2 = tr["d_optim"].state_dict(), tr2["d_optim"].state_dict()
+    assert s1["param_groups"] == s2["param_groups"]
+    assert all(torch.equal(s1["state"][i]["exp_avg_sq"], s2["state"][i]["exp_avg_sq"]) for i in s1["state"])
