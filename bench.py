@@ -84,13 +84,31 @@ def roofline_probe(device, batch: int, launches: int):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     wino = CV.WINOGRAD
+    traffic, traffic_note = _pmc_traffic() if (wino and batch == 32) else (None, None)
     kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino
               else "conv_igemm_kernel<2,2,2,2,true,false,true> (direct implicit GEMM)")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
             "kernel": kernel + " on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch,
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
             "mfma_executed_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4)}
+
+
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.csv;
+    the counters cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 reports half the bytes of a wide
+    coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB."""
+    import csv
+    try:
+        vals = {}
+        for name, fn in (("FETCH_SIZE", "r01_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_pmc_write_size.csv")):
+            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn)))
+                    if r["Counter_Name"] == name and "wino" in r["Kernel_Name"]]
+            vals[name] = sum(rows) / len(rows)
+        return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
+            "profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv (separate --pmc passes; FETCH_SIZE x2)"
+    except Exception:
+        return None, None
 
 
 def _cpu_baseline_worker(R: int, threads: int):
