@@ -504,20 +504,23 @@ def run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco):
 
 
 def gen_step(RM, RU, RL, RO, which):
+    N = 1
     if which == "r64":
         R, B, n_iters, zero_dco = 64, 2, 2, True
+    elif which == "r64_N2":                      # BASELINE.json configs[3]/[4]: N = 2 (two secret channels)
+        R, B, n_iters, zero_dco, N = 64, 2, 1, True, 2
     else:
         R, B, n_iters, zero_dco = 256, 1, 2, False
-    args = tiny_args(R)
+    args = tiny_args(R, N=N)
     args.__dict__.update(num_iters=n_iters, start_iter=0, lambda_Ex=10.0, lr=0.002, batch_size=B, real_r1=10.0,
                          texture_r1=1.0, dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=2,
                          log_every=1, show_every=n_iters, save_every=10 ** 9)
-    seed = 77 if which == "r64" else 78
+    seed = {"r64": 77, "r64_N2": 79}.get(which, 78)
     gx = torch.Generator().manual_seed(seed + 100)
     X = torch.rand(B, 3, R, R, generator=gx) * 2 - 1
     trainer, draws, log, losses, test_lines = run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco)
     out = {"X": npy(X), "seed": np.array(seed)}
-    out["meta"] = np.array(json.dumps(dict(R=R, B=B, n_iters=n_iters, zero_dco=zero_dco, d_reg_every=2, channel=4,
+    out["meta"] = np.array(json.dumps(dict(R=R, B=B, N=N, n_iters=n_iters, zero_dco=zero_dco, d_reg_every=2, channel=4,
                                            texture_channel=64, cm_den=8, test_lines=test_lines,
                                            opt_log=[[n_, len(v)] for n_, v in log])))
     for i, z in enumerate(draws["Z"]):
@@ -549,7 +552,7 @@ def gen_step(RM, RU, RL, RO, which):
 
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["ops", "nets", "init", "step_r64", "step_r256"]
+    todo = sys.argv[1:] or ["ops", "nets", "init", "step_r64", "step_r256", "step_r64_N2"]
     mods = import_reference()
     torch.set_num_threads(8)
     if "ops" in todo:
@@ -562,3 +565,5 @@ if __name__ == "__main__":
         gen_step(*mods, "r64")
     if "step_r256" in todo:
         gen_step(*mods, "r256")
+    if "step_r64_N2" in todo:
+        gen_step(*mods, "r64_N2")

@@ -1,6 +1,7 @@
 """GPU parity of the seven networks (tiny width) and of the training step against the reference's vectors."""
 import argparse
 import json
+import os
 
 import numpy as np
 import pytest
@@ -121,7 +122,7 @@ def replay_step(which, device, build_nets=None):
     meta = g.json("meta")
     R, B = meta["R"], meta["B"]
     args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=R, batch_size=B,
-                           d_reg_every=2, num_iters=meta["n_iters"], use_dco=True)
+                           d_reg_every=2, num_iters=meta["n_iters"], use_dco=True, N=meta.get("N", 1))
     torch.manual_seed(int(g.t("seed")))
     trainer = TS.build_trainer(args, "cpu", init_model, dco_factory=(ZeroDco if meta["zero_dco"] else None))
     if build_nets is not None:
@@ -190,7 +191,7 @@ def check_replay(g, meta, trainer, out, log):
         assert abs(a - a_ref) <= 1e-5 * a_ref + 1e-9, (name, a, a_ref)
 
 
-@pytest.mark.parametrize("which", ["r64", "r256"])
+@pytest.mark.parametrize("which", ["r64", "r256", "r64_N2"])
 def test_step_replay_gpu(which):
     g, meta, trainer, out, log = replay_step(which, "cuda")
     check_replay(g, meta, trainer, out, log)
@@ -289,3 +290,42 @@ def test_train_iteration_with_path_length_and_literal_second_backward():
     assert "path_loss" in losses and float(losses["path_length"]) > 0
     after = torch.cat([p.detach().flatten() for p in tr["G"].parameters()])
     assert float((after - before).abs().max()) > 0
+
+
+
+def test_full_width_chain_vs_oracle():
+    """Full-width networks at 256x256 (the bench's architecture: 512-channel layers, 2048-d texture), B=1:
+    E -> (Gstru) -> G -> E -> Ex on the GPU vs the CPU oracle on the same seeded weights; plus Dreal / Ddist logits."""
+    import oracle.torch_ref as O
+    from ideas_amd import train_step as TS
+    from ideas_amd.models import init_model
+    args = TS.default_args(image_size=256)
+    torch.manual_seed(0)
+    nets = {n: init_model(TS.NET_CLASSES[n], args) for n in ("E", "G", "Gstru", "Ex", "Dreal", "Ddist")}
+    X = torch.rand(1, 3, 256, 256) * 2 - 1
+    Z = torch.rand(1, 1, 16, 16) * 2 - 1
+    cfg = O.Cfg(image_size=256)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    with torch.no_grad():
+        P = {n: {k: v.detach().contiguous() for k, v in m.state_dict().items()} for n, m in nets.items()}
+        S1, T1 = O.encoder(P["E"], cfg, X)
+        S2 = O.structure_generator(P["Gstru"], cfg, Z)
+        img = O.generator(P["G"], cfg, S2, T1)
+        hS2, _ = O.encoder(P["E"], cfg, img)
+        hZ = O.extractor(P["Ex"], cfg, hS2)
+        dlog = O.image_discriminator(P["Dreal"], cfg, img)
+        tlog = O.distribution_discriminator(P["Ddist"], cfg, T1)
+        for m in nets.values():
+            m.cuda()
+        Xd = X.cuda()
+        S1d, T1d = nets["E"](Xd)
+        S2d = nets["Gstru"](Z.cuda())
+        imgd = nets["G"](S2d, T1d)
+        hS2d, _ = nets["E"](imgd)
+        hZd = nets["Ex"](hS2d)
+        dlogd = nets["Dreal"](imgd)
+        tlogd = nets["Ddist"](T1d)
+    for name, a, b in (("S1", S1d, S1), ("T1", T1d, T1), ("S2", S2d, S2), ("img", imgd, img), ("hat_S2", hS2d, hS2),
+                       ("hat_Z", hZd, hZ), ("Dreal", dlogd, dlog), ("Ddist", tlogd, tlog)):
+        assert rel_err(a, b) < 2e-5, (name, rel_err(a, b))
+    assert torch.equal(hZd.cpu() >= 0, hZ >= 0), "secret-bit decisions differ at full width"
