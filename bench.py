@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--N", type=int, default=1)
     p.add_argument("--literal-second-backward", action="store_true",
                    help="re-traverse Ex->E->G->Gstru for the Ex gradient exactly like train.py:214-215")
+    p.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + per-tensor EMA instead of FusedAdamEMA")
     p.add_argument("--cpu-baseline", choices=["auto", "skip"], default="auto")
     p.add_argument("--roofline", choices=["on", "off", "only"], default="on")
     p.add_argument("--roofline-launches", type=int, default=20)
@@ -211,6 +212,9 @@ def main():
     for v in trainer.values():
         if isinstance(v, torch.nn.Module):
             v.to(device)
+    if not a.torch_adam:
+        from ideas_amd.optim import fuse_optimizers
+        fuse_optimizers(trainer, args)      # one fused Adam(beta1=0)+EMA launch per group on flat buffers
     random.seed(1000 + rank)
     torch.manual_seed(1000 + rank)
     gx = torch.Generator().manual_seed(1234 + rank)

@@ -57,6 +57,19 @@ def _dense(p: torch.Tensor) -> bool:
     return expect == n
 
 
+def _adopt_flat(params: Sequence[torch.Tensor]):
+    """If a FusedAdamEMA owns these parameters, its flat gradient buffer IS the bucket (padding stays zero)."""
+    from .optim import FLAT_GRADS
+    entry = FLAT_GRADS.get(id(params[0])) if len(params) else None
+    if entry is None:
+        return None
+    flat, owner = entry
+    if len(owner._params) != len(params) or any(a is not b for a, b in zip(owner._params, params)):
+        return None
+    owner._rebind_grads()
+    return flat
+
+
 class GradReducer:
     """``reducer(tag, params)`` callback for ``train_iteration``: averages the step's gradients over ranks.
 
@@ -83,6 +96,13 @@ class GradReducer:
 
     def __call__(self, tag: str, params: Sequence[torch.Tensor]) -> None:
         if not dist.is_available() or not dist.is_initialized():
+            return
+        flat = _adopt_flat(params)
+        if flat is not None:                      # zero-copy: the optimiser's flat gradient buffer is the bucket
+            world = dist.get_world_size(self.group)
+            if world > 1:
+                flat.div_(world)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return
         b = self.bucket_for(tag, params)
         # a backward may have replaced .grad (set_to_none paths); fold strays back into the bucket

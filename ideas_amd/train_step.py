@@ -163,7 +163,7 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         d_total = d_total + losses["D_texture_loss"]
     losses["D_dist_loss"] = d_logistic_loss(T["Ddist"](T2), T["Ddist"](T1))
     d_total = d_total + losses["D_dist_loss"]
-    T["d_optim"].zero_grad(set_to_none=False)
+    T["d_optim"].zero_grad()
     d_total.backward()
     _sync("d", d_params)
     T["d_optim"].step()
@@ -182,7 +182,7 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         T2r = T2.detach().requires_grad_(True)
         losses["D_dist_r1_loss"] = d_r1_loss(T["Ddist"](T2r), T2r)
         r1 = r1 + args.dist_r1 / 3 * losses["D_dist_r1_loss"] * args.d_reg_every
-        T["d_optim"].zero_grad(set_to_none=False)
+        T["d_optim"].zero_grad()
         r1.backward()
         _sync("r1", d_params)
         T["d_optim"].step()
@@ -222,12 +222,14 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
     losses["hat_Z"] = hat_Z.detach()
 
     if args.elide_second_backward:
-        ex_grads = torch.autograd.grad(losses["Ex_loss"], ex_params, retain_graph=True)
-        g_grads = torch.autograd.grad(loss_total, g_params, allow_unused=True)
-        _set_grads(g_params, g_grads)
+        # Ex's gradient over the Ex sub-graph only, everything else from Loss_total; both accumulate IN PLACE into the
+        # optimisers' gradient buffers (flat buckets when the fused optimiser / DDP reducer own them)
+        T["ex_optim"].zero_grad()
+        T["g_optim"].zero_grad()
+        torch.autograd.backward(losses["Ex_loss"], inputs=ex_params, retain_graph=True)
+        torch.autograd.backward(loss_total, inputs=g_params)
         _sync("g", g_params)
         T["g_optim"].step()
-        _set_grads(ex_params, ex_grads)
         _sync("ex", ex_params)
         T["ex_optim"].step()
     else:
@@ -254,10 +256,11 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         losses.update(path_length_step(T, args, X.shape[0], X.shape[-1], X.device, reducer=reducer))
 
     # ------------------------------------------------------------------ EMA (train.py:218-221)
-    accum = 0.5 ** (32 / (10 * 1000))
-    for n in EMA_NETS:
-        if n + "_ema" in T:
-            accumulate(T[n + "_ema"], T[n], accum)
+    if not T.get("_fused_ema", False):       # FusedAdamEMA (ideas_amd/optim.py) already updated the EMA copies
+        accum = 0.5 ** (32 / (10 * 1000))
+        for n in EMA_NETS:
+            if n + "_ema" in T:
+                accumulate(T[n + "_ema"], T[n], accum)
     return losses
 
 

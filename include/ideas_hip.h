@@ -166,6 +166,13 @@ int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, 
 int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out, const float* bias,
                       int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
 
+/* Fused Adam (beta1 = 0, as every optimiser of train.py:417-432) + optional EMA (utils.py:55-60) over ONE flat f32
+ * buffer aliasing all parameters of an optimiser group (n % 4 == 0, 16-byte aligned):
+ *     v = beta2*v + (1-beta2)*g*g;  p -= lr * g / (sqrt(v)/sqrt(bias_correction2) + eps);  ema = d*ema + (1-d)*p
+ * bias_correction2 = 1 - beta2^step (computed by the caller); ema may be NULL. */
+int ideas_adam_ema(float* p, const float* g, float* v, float* ema, int64_t n, float lr, float beta2, float eps,
+                   float bias_correction2, float ema_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,7 +114,7 @@ class ZeroDco(torch.nn.Module):
         return o, o
 
 
-def replay_step(which, device, build_nets=None):
+def replay_step(which, device, build_nets=None, fuse=None):
     """Shared by the GPU test and (with oracle-backed nets) the CPU host-logic test."""
     from ideas_amd import train_step as TS
     from ideas_amd.models import init_model
@@ -131,6 +131,8 @@ def replay_step(which, device, build_nets=None):
         for k, v in trainer.items():
             if isinstance(v, torch.nn.Module):
                 v.to(device)
+        if fuse is not None:
+            fuse(trainer, args)
     X = g.t("X").to(device)
     s = R // 16
     zi = ti = bi = oi = 0
@@ -329,3 +331,52 @@ def test_full_width_chain_vs_oracle():
                        ("hat_Z", hZd, hZ), ("Dreal", dlogd, dlog), ("Ddist", tlogd, tlog)):
         assert rel_err(a, b) < 2e-5, (name, rel_err(a, b))
     assert torch.equal(hZd.cpu() >= 0, hZ >= 0), "secret-bit decisions differ at full width"
+
+
+def test_fused_adam_ema_matches_torch_adam_and_accumulate():
+    """ideas_adam_ema (one launch per group, EMA fused) vs torch.optim.Adam(betas=(0, .99)) + utils.accumulate on the
+    same random gradients for several steps, including a checkpoint round trip through the torch-Adam state-dict format."""
+    from ideas_amd.optim import FusedAdamEMA
+    from ideas_amd.utils import accumulate
+    torch.manual_seed(0)
+    shapes = [(16, 8, 3, 3), (16,), (5, 7), (1, 4, 8, 3, 3), (3,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    ref, fus = mk(), None
+    ref[0].data = ref[0].data.contiguous(memory_format=CL)
+    fus = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    ref_ema = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    fus_ema = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    decay = 0.5 ** (32 / 10000)
+    r = 16 / 17
+    o_ref = torch.optim.Adam(ref, lr=0.002 * r, betas=(0.0, 0.99 ** r))
+    o_fus = FusedAdamEMA(fus, lr=0.002 * r, betas=(0.0, 0.99 ** r), ema_params=fus_ema, ema_decay=decay)
+
+    class M(torch.nn.Module):
+        def __init__(self, ps):
+            super().__init__()
+            self.ps = torch.nn.ParameterList(ps)
+    for step in range(5):
+        o_ref.zero_grad(); o_fus.zero_grad()
+        for a, b in zip(ref, fus):
+            gsrc = torch.randn_like(a) * (10.0 ** (-step))
+            a.grad = gsrc.clone()
+            b.grad.add_(gsrc)                      # in-place accumulation into the flat buffer, as backward does
+        o_ref.step(); o_fus.step()
+        accumulate(M(ref_ema), M(ref), decay)
+        if step == 2:                              # checkpoint round trip in torch's Adam format
+            sd = o_fus.state_dict()
+            assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+            o_fus.load_state_dict(sd)
+        for a, b in zip(ref, fus):
+            assert rel_err(b, a) < 2e-6
+        for a, b in zip(ref_ema, fus_ema):
+            assert rel_err(b, a) < 2e-6
+    for a, b in zip(o_ref.state_dict()["state"].values(), o_fus.state_dict()["state"].values()):
+        assert rel_err(b["exp_avg_sq"], a["exp_avg_sq"]) < 2e-6
+
+
+def test_step_replay_gpu_with_fused_optimizers():
+    """The r256 reference step replay again, with FusedAdamEMA driving all three groups and the EMA copies."""
+    from ideas_amd.optim import fuse_optimizers
+    g, meta, trainer, out, log = replay_step("r256", "cuda", fuse=fuse_optimizers)
+    check_replay(g, meta, trainer, out, log)
