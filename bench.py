@@ -31,9 +31,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 PEAK_HBM_GBS = 8000.0
 
 
-def flop_per_image(elided: bool, d_reg_every: int = 16) -> float:
-    """Algorithmic GFLOP per image per iteration at R=256 (rule: bwd with weight+input grads = 2F, input-only = 1F)."""
-    d_phase = (F_E + F_GS + 3 * F_G + 4 * F_DR + 48 * F_DC) + 2 * (4 * F_DR + 48 * F_DC)
+def flop_per_image(elided: bool, d_reg_every: int = 16, shared: bool = True) -> float:
+    """Algorithmic GFLOP per image per iteration at R=256 (rule: bwd with weight+input grads = 2F, input-only = 1F).
+    `shared`: E(X) and G(S1,T1) evaluated once per iteration instead of once per phase (train_step.share_forward)."""
+    d_phase = ((0.0 if shared else F_E + F_G) + F_GS + 2 * F_G + 4 * F_DR + 48 * F_DC) + 2 * (4 * F_DR + 48 * F_DC)
     g_fwd = 2 * F_E + F_GS + 3 * F_G + 3 * F_DR + 40 * F_DC + F_EX
     g_bwd = 2 * (2 * F_E + F_GS + 3 * F_G + F_EX) + 3 * F_DR + 8 * F_DC
     second = 0.0 if elided else 2 * (F_EX + F_E + F_G + F_GS) + 2 * F_E
@@ -51,6 +52,8 @@ def parse():
     p.add_argument("--N", type=int, default=1)
     p.add_argument("--literal-second-backward", action="store_true",
                    help="re-traverse Ex->E->G->Gstru for the Ex gradient exactly like train.py:214-215")
+    p.add_argument("--no-share-forward", action="store_true",
+                   help="evaluate E(X) and G(S1,T1) in both phases like train.py:58,68,145,155 (same results, +4.6 %% FLOPs)")
     p.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam + per-tensor EMA instead of FusedAdamEMA")
     p.add_argument("--cpu-baseline", choices=["auto", "skip"], default="auto")
     p.add_argument("--roofline", choices=["on", "off", "only"], default="on")
@@ -206,7 +209,8 @@ def main():
         return
 
     args = TS.default_args(image_size=a.image_size, batch_size=a.batch, N=a.N,
-                           elide_second_backward=not a.literal_second_backward, num_iters=10 ** 9)
+                           elide_second_backward=not a.literal_second_backward, num_iters=10 ** 9,
+                           share_forward=not a.no_share_forward)
     torch.manual_seed(0)              # identical replicas on every rank (no broadcast needed)
     trainer = TS.build_trainer(args, "cpu", init_model)
     for v in trainer.values():
@@ -248,7 +252,7 @@ def main():
 
     n_r1 = sum(1 for i in range(1, a.steps + 1) if i % args.d_reg_every == 0)
     ips = world * a.batch * a.steps / dt
-    gflop_img = flop_per_image(not a.literal_second_backward)
+    gflop_img = flop_per_image(not a.literal_second_backward, shared=not a.no_share_forward)
     out = {
         "metric": "train images/sec at 256x256 (G+D+Ex step)", "value": round(ips, 3), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -256,7 +260,8 @@ def main():
         "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
                                "full-width nets, HIP kernels (BASELINE.json configs[2])" % (a.N, a.image_size, a.image_size, a.batch),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
-                   "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)"},
+                   "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
+                   "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off"},
         "step_gflop_per_image": round(gflop_img, 1),
         "step_mfma_frac": round(ips / world * gflop_img / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
         "losses": {k: round(float(v), 4) for k, v in losses.items() if v.numel() == 1},

@@ -44,16 +44,32 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_v4(float4* __restrict__ y, 
         for (int c = threadIdx.x; c < C; c += blockDim.x) s_bg[c] = 0.f;
         __syncthreads();
     }
-    for (int64_t i = tid; i < n4; i += stride) {
-        float4 v = x[i];
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (HAS_REF) r = ref[i];
-        if (HAS_B) { v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-        float4 o;
-        o.x = act_one(v.x, r.x, a); o.y = act_one(v.y, r.y, a);
-        o.z = act_one(v.z, r.z, a); o.w = act_one(v.w, r.w, a);
-        y[i] = o;
-        if (BGRAD) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    // 4 independent 16-byte loads (8 with ref) in flight per thread per trip: one load per trip leaves the kernel
+    // latency-bound at ~4.6 TB/s; the channel a thread owns is unchanged because every offset is a multiple of `stride`
+    constexpr int U = 4;
+    for (int64_t i0 = tid; i0 < n4; i0 += U * stride) {
+        float4 v[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+                v[u] = x[i];
+                if (HAS_REF) r[u] = ref[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n4) break;
+            float4 vv = v[u];
+            float4 rr = HAS_REF ? r[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (HAS_B) { vv.x += bb.x; vv.y += bb.y; vv.z += bb.z; vv.w += bb.w; }
+            float4 o;
+            o.x = act_one(vv.x, rr.x, a); o.y = act_one(vv.y, rr.y, a);
+            o.z = act_one(vv.z, rr.z, a); o.w = act_one(vv.w, rr.w, a);
+            y[i] = o;
+            if (BGRAD) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+        }
     }
     if (BGRAD) {
         if (tid < n4) {

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_igemm_kernel(float* _
 //   MFMA operands are read with conflict-free ds_read_b32.  The pixel axis is split over blockIdx.y
 //   (split-K); partial tiles are combined with f32 atomics into the caller-zeroed gw.
 // =====================================================================================================
-template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT, bool WIDEW>
 __global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ in_scale,
@@ -353,9 +353,18 @@ __global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_wgrad_kernel(float* _
     auto walk_step = [&](Walk& wk) {
         wk.left -= BK;
         wk.ox += BK;
-        while (wk.ox >= p.OW) {
-            wk.ox -= p.OW;
-            if (++wk.oy == p.OH) { wk.oy = 0; ++wk.b; }
+        if (WIDEW) {   // OW >= BK: at most one row boundary per step -> selects only (single-basic-block K loop)
+            const bool wrap = wk.ox >= p.OW;
+            wk.ox -= wrap ? p.OW : 0;
+            wk.oy += wrap ? 1 : 0;
+            const bool wrap2 = wk.oy == p.OH;
+            wk.oy = wrap2 ? 0 : wk.oy;
+            wk.b += wrap2 ? 1 : 0;
+        } else {
+            while (wk.ox >= p.OW) {
+                wk.ox -= p.OW;
+                if (++wk.oy == p.OH) { wk.oy = 0; ++wk.b; }
+            }
         }
     };
     Walk gwk[G_PER], xwk[X_PER];
@@ -428,12 +437,16 @@ __global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_wgrad_kernel(float* _
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int64_t nsteps = (pend - pbeg + BK - 1) / BK;
+    // same pipeline as the forward kernel: registers hold step s+1 at the top (-> LDS[buf^1]), the loads of step s+2
+    // are issued before the MFMAs of step s; rows beyond `pend` are predicated off, so no bounds branch
     gload();
     lstore(0);
+    gload();
     __syncthreads();
     for (int64_t s = 0; s < nsteps; ++s) {
         const int buf = (int)(s & 1);
-        if (s + 1 < nsteps) gload();
+        lstore(buf ^ 1);
+        gload();
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             float av[MT], bv[NT];
@@ -447,8 +460,6 @@ __global__ __launch_bounds__(256, SCALE ? 3 : 4) void conv_wgrad_kernel(float* _
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
@@ -515,8 +526,8 @@ int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_s
     static int occ_cache[2] = {0, 0};
     if (!occ_cache[sc_]) {
         int occ = 0;
-        hipError_t e = sc_ ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_kernel<WM, WN, MT, NT, true, false>, 256, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_kernel<WM, WN, MT, NT, false, false>, 256, 0);
+        hipError_t e = sc_ ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_kernel<WM, WN, MT, NT, true, false, true>, 256, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_kernel<WM, WN, MT, NT, false, false, true>, 256, 0);
         occ_cache[sc_] = (e == hipSuccess && occ > 0) ? occ : 2;
     }
     static int n_cu = 0;
@@ -546,9 +557,14 @@ int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_s
         }
     }
     auto go = [&](auto sc, auto rf) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
-                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const float*)gy,
-                           (const float*)x, in_scale, out_scale, *p, tn, per);
+        if (p->OW >= BK)
+            hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value, true>),
+                               dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const float*)gy,
+                               (const float*)x, in_scale, out_scale, *p, tn, per);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value, false>),
+                               dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const float*)gy,
+                               (const float*)x, in_scale, out_scale, *p, tn, per);
     };
     using T = std::true_type;
     using F = std::false_type;

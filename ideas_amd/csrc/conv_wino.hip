@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(float* __restrict_
 // =====================================================================================================
 constexpr int GBM = 64, GBN = 128, GBK = 8;
 
-template <bool SCALE, bool REFLECT>
+template <bool SCALE, bool REFLECT, bool WIDEW>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_wgrad_kernel(float* __restrict__ gu, const float* __restrict__ gy,
                                                                     const float* __restrict__ x,
                                                                     const float* __restrict__ in_scale,
@@ -278,9 +278,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_wgrad_kernel(float* __res
     auto walk_step = [&](Walk& wk) {
         wk.left -= GBK;
         wk.tx += GBK;
-        while (wk.tx >= W2) {
-            wk.tx -= W2;
-            if (++wk.y == H) { wk.y = 0; ++wk.b; }
+        if (WIDEW) {   // W/2 >= GBK: at most one row boundary per step -> selects only, the K loop stays one basic block
+            const bool wrap = wk.tx >= W2;
+            wk.tx -= wrap ? W2 : 0;
+            wk.y += wrap ? 1 : 0;
+            const bool wrap2 = wk.y == H;
+            wk.y = wrap2 ? 0 : wk.y;
+            wk.b += wrap2 ? 1 : 0;
+        } else {
+            while (wk.tx >= W2) {
+                wk.tx -= W2;
+                if (++wk.y == H) { wk.y = 0; ++wk.b; }
+            }
         }
     };
     // G items: threads 0..127 -> (pair row pr = t/16, channel quad oq = t%16)
@@ -473,9 +482,14 @@ extern "C" int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x
         }
     }
     auto go = [&](auto sc, auto rf) {
-        hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<decltype(sc)::value, decltype(rf)::value>),
-                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gu, (const float*)gy,
-                           (const float*)x, in_scale, out_scale, *p, tn, per);
+        if (p->IW / 2 >= GBK)
+            hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<decltype(sc)::value, decltype(rf)::value, true>),
+                               dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gu, (const float*)gy,
+                               (const float*)x, in_scale, out_scale, *p, tn, per);
+        else
+            hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<decltype(sc)::value, decltype(rf)::value, false>),
+                               dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gu, (const float*)gy,
+                               (const float*)x, in_scale, out_scale, *p, tn, per);
     };
     using T = std::true_type;
     using F = std::false_type;

@@ -1,0 +1,50 @@
+// Adjoint of ReflectionPad2d(p) (models.py:102-106) in NHWC: folds the gradient of the padded tensor
+// [B, H+2p, W+2p, C] back onto [B, H, W, C] in one pass.  Row y of the input appears in the padded tensor at
+// y+p, and additionally at p-y (for 1 <= y <= p) and at 2(H-1)+p-y (for H-1-p <= y <= H-2); same for columns.
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void reflect_fold_kernel(float4* __restrict__ gx, const float4* __restrict__ gp, int B,
+                                                           int H, int W, int C4, int pad) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int64_t r = i;
+        const int c = (int)(r % C4); r /= C4;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + pad;
+        if (y >= 1 && y <= pad) ys[ny++] = pad - y;
+        if (y >= H - 1 - pad && y <= H - 2) ys[ny++] = 2 * (H - 1) + pad - y;
+        xs[nx++] = x + pad;
+        if (x >= 1 && x <= pad) xs[nx++] = pad - x;
+        if (x >= W - 1 - pad && x <= W - 2) xs[nx++] = 2 * (W - 1) + pad - x;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e) {
+                const float4 v = gp[(((int64_t)b * Hp + ys[a]) * Wp + xs[e]) * C4 + c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        gx[i] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int ideas_reflect_fold(void* gx, const void* gpadded, int B, int H, int W, int C, int pad, int dtype,
+                                  void* stream) {
+    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (!gx || !gpadded) return IDEAS_E_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad <= 0 || pad >= H || pad >= W) return IDEAS_E_SHAPE;
+    if ((C & 3) || !ideas_aligned16(gx) || !ideas_aligned16(gpadded)) return IDEAS_E_ALIGN;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    int64_t grid = ideas_cdiv(total, 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float4*)gx,
+                       (const float4*)gpadded, B, H, W, C / 4, pad);
+    return ideas_launch_status();
+}

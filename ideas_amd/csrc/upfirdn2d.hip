@@ -115,20 +115,33 @@ __global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const 
     load_row(iy0 + 1, w[1]);
     load_row(iy0 + 2, w[2]);
     float4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
-    for (int oy = oy0; oy < oy1; ++oy) {
-        load_row(oy - p.pad_y0 + 3, w[3]);
+    auto emit = [&](int oy, const float4 (&r0)[4], const float4 (&r1)[4], const float4 (&r2)[4], const float4 (&r3)[4]) {
         float4 acc = zero;
 #pragma unroll
-        for (int ry = 0; ry < 4; ++ry)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float kk = k[ry * 4 + t];
-                acc.x += w[ry][t].x * kk; acc.y += w[ry][t].y * kk;
-                acc.z += w[ry][t].z * kk; acc.w += w[ry][t].w * kk;
-            }
+        for (int t = 0; t < 4; ++t) {
+            const float k0 = k[t], k1 = k[4 + t], k2 = k[8 + t], k3 = k[12 + t];
+            acc.x += r0[t].x * k0 + r1[t].x * k1 + r2[t].x * k2 + r3[t].x * k3;
+            acc.y += r0[t].y * k0 + r1[t].y * k1 + r2[t].y * k2 + r3[t].y * k3;
+            acc.z += r0[t].z * k0 + r1[t].z * k1 + r2[t].z * k2 + r3[t].z * k3;
+            acc.w += r0[t].w * k0 + r1[t].w * k1 + r2[t].w * k2 + r3[t].w * k3;
+        }
         yb[(int64_t)oy * p.out_w * C4] = acc;
+    };
+    // two output rows per trip: 8 independent 16-byte loads in flight instead of 4 (the window shift is a
+    // dependent chain, so one row per trip is latency-bound)
+    float4 w4[4];
+    int oy = oy0;
+    for (; oy + 1 < oy1; oy += 2) {
+        load_row(oy - p.pad_y0 + 3, w[3]);
+        load_row(oy - p.pad_y0 + 4, w4);
+        emit(oy, w[0], w[1], w[2], w[3]);
+        emit(oy + 1, w[1], w[2], w[3], w4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { w[0][t] = w[1][t]; w[1][t] = w[2][t]; w[2][t] = w[3][t]; }
+        for (int t = 0; t < 4; ++t) { w[0][t] = w[2][t]; w[1][t] = w[3][t]; w[2][t] = w4[t]; }
+    }
+    if (oy < oy1) {
+        load_row(oy - p.pad_y0 + 3, w[3]);
+        emit(oy, w[0], w[1], w[2], w[3]);
     }
 }
 

@@ -166,6 +166,11 @@ int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, 
 int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out, const float* bias,
                       int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
 
+/* Adjoint of ReflectionPad2d(pad) in NHWC: gx [B,H,W,C] = fold of gpadded [B,H+2pad,W+2pad,C] (mirrored border rows /
+ * columns added back onto their sources).  C % 4 == 0.  Used by the input gradient of the reflect-padded 3x3 convs of
+ * E / Gstru / Ex (models.py:102-106). */
+int ideas_reflect_fold(void* gx, const void* gpadded, int B, int H, int W, int C, int pad, int dtype, void* stream);
+
 /* Fused Adam (beta1 = 0, as every optimiser of train.py:417-432) + optional EMA (utils.py:55-60) over ONE flat f32
  * buffer aliasing all parameters of an optimiser group (n % 4 == 0, 16-byte aligned):
  *     v = beta2*v + (1-beta2)*g*g;  p -= lr * g / (sqrt(v)/sqrt(bias_correction2) + eps);  ema = d*ema + (1-d)*p

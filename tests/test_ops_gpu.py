@@ -448,3 +448,19 @@ def test_full_size_blur_and_bias_act_properties():
     assert rel_err(gb, gxa.double().sum(dim=(0, 2, 3))) < 5e-5
     pos = out.detach() > 0
     assert torch.allclose(gxa[pos], torch.full_like(gxa[pos], 2 ** 0.5)) and torch.allclose(gxa[~pos], torch.full_like(gxa[~pos], 0.2 * 2 ** 0.5))
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 8, 6, 9), 1), ((1, 32, 34, 34), 1), ((2, 4, 5, 4), 2)])
+def test_reflect_fold_is_the_adjoint_of_reflection_pad(shape, pad):
+    """ideas_reflect_fold (input-gradient fold of the reflect-padded convs) == autograd of F.pad(mode='reflect')."""
+    from ideas_amd import _lib
+    B, C, H, W = shape
+    torch.manual_seed(sum(shape))
+    gp = torch.randn(B, C, H + 2 * pad, W + 2 * pad, dtype=torch.float64)
+    x = torch.zeros(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.pad(x, [pad] * 4, mode="reflect"), x, gp)
+    gpd = dev(gp.float(), True)
+    out = torch.empty((B, C, H, W), device="cuda", memory_format=CL)
+    rc = _lib.load().ideas_reflect_fold(_lib.ptr(out), _lib.ptr(gpd), B, H, W, C, pad, _lib.F32, _lib.stream_ptr())
+    assert rc == 0
+    assert rel_err(out, ref) < 1e-6
