@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("IDEAS_HIP_LIB", os.path.join(_HERE, "libideas_hip.so"
 
 NCHW, NHWC = 0, 1
 F32 = 0
+F32_B3 = 1   # f32 tensors, split-bf16 contraction (IDEAS_F32_B3)
 
 
 class ConvParams(C.Structure):
@@ -42,6 +43,8 @@ _PROTOS = {
                                        C.c_float, C.c_float, C.c_int, _P]),
     "ideas_upfirdn2d": (C.c_int, [_P, _P, _P] + [C.c_int] * 14 + [C.c_float, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_conv_igemm": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
+    "ideas_b3_conv_supported": (C.c_int, [C.POINTER(ConvParams)]),
+    "ideas_b3_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "ideas_conv3x3_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv3x3_wino_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv_direct": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),

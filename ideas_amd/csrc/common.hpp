@@ -39,3 +39,8 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 #pragma clang fp contract(off)
     return a * b;
 }
+
+// conv_b3.hip: forward-family implicit GEMM with the bf16x3 split contraction (arguments already validated;
+// `wplanes` from ideas_b3_split_weights)
+int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
+                 const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);

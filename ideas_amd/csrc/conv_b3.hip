@@ -1,0 +1,385 @@
+// Implicit-GEMM convolution on the gfx950 bf16 matrix pipe with f32-class accuracy ("bf16x3"), NHWC, f32 in/out.
+//
+// Same GEMM view and epilogue as conv_igemm.hip (which runs the contraction on v_mfma_f32_32x32x2_f32 = 1/16 of
+// the bf16 MFMA rate).  Here every f32 operand is split into three bf16 planes
+//
+//        x = hi + mid + lo        hi = rne_bf16(x),  mid = rne_bf16(x - hi),  lo = x - hi - mid
+//
+// The split is EXACT (both residuals are exact f32 subtractions, and lo has <= 8 significant bits left), so
+//        x*w = sum over the 9 plane pairs, each an exact bf16 x bf16 product accumulated in f32 by the MFMA.
+// Six pairs are contracted (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) with v_mfma_f32_32x32x16_bf16; the three
+// dropped pairs (mid.lo, lo.mid, lo.lo) are each <= 2^-24 |x*w|, the size of the f32 rounding of the product itself.
+// Measured against f64 (tools/gemm_bf16x3.hip, tools/check_b3.py): max / rms error equal to the exact f32 MFMA
+// kernel's (2.2-2.8e-7 / 2.5e-8 of sum|x*w| against 2.0-3.0e-7 / 2.5-3.2e-8).  Six bf16 MFMAs replace sixteen f32 ones.
+//
+// The matrix pipe is then no longer the only limiter: a SIMD issues the split arithmetic through the same VALU port
+// as the MFMAs, so the kernel is built to keep everything else OFF the vector ALU:
+//   * weights are split once per launch by ideas_b3_split_weights into step-major planes [3][K/16][Cout][16] bf16:
+//     the B tile of a K-step is one contiguous 4 KB block, copied global -> LDS without any arithmetic;
+//   * activations are fetched with raw buffer loads: 32-bit offsets, and padding taps get an out-of-range offset,
+//     for which the hardware returns zeros (no predication, no zero-fill selects);
+//   * the (tap, ci) walk is block-uniform -> scalar ALU; per row a K-step costs a bit-field extract of the row's
+//     precomputed invalid-tap mask, an add and an or;
+//   * rows beyond M and columns beyond Cout are not masked at all: their operands are duplicates / whatever the
+//     buffer returns, and their results are simply not stored (rows and columns of a GEMM are independent).
+// What is left on the VALU per 16 x 16-element A chunk: 6 cvt_pk + 8 bit ops + 8 subtractions (+4 mul for the
+// modulation scale).
+//
+// LDS: per pipeline buffer three A planes [BM][16 bf16] and three B planes [BN][16 bf16]; 32-byte rows with the two
+// 16-byte halves swapped on rows with bit 3 set: ds_write_b64 (staging), ds_write_b128 (weights) and the
+// ds_read_b128 operand fetch are all conflict-free (checked by enumeration against the bank rules of
+// MI355X_MICROARCH.md).  Lane (i = lane&31, h = lane>>5) of a 32x32x16 MFMA holds K values [8h, 8h+8) of row i.
+#include "common.hpp"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 16;     // f32 K depth of one pipeline step = K of one bf16 MFMA
+constexpr int ROWB = 32;   // bytes per LDS row (16 bf16)
+constexpr unsigned RSRC_FLAGS = 0x00020000u;   // raw buffer, 32-bit data format
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
+    const int q = nblk >> 3, rem = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
+// two f32 -> one dword of two RNE bf16 (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float lo_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float hi_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+
+// exact three-way split of four f32 into packed bf16 planes
+struct Split4 { uint2 p[3]; };
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16(a, b);
+    const float ra = a - lo_f32(h), rb = b - hi_f32(h);
+    m = pack_bf16(ra, rb);
+    l = pack_bf16(ra - lo_f32(m), rb - hi_f32(m));   // exact: <= 8 significant bits are left
+}
+__device__ __forceinline__ Split4 split4(float4 v) {
+    Split4 s;
+    split2(v.x, v.y, s.p[0].x, s.p[1].x, s.p[2].x);
+    split2(v.z, v.w, s.p[0].y, s.p[1].y, s.p[2].y);
+    return s;
+}
+
+// (bit_cast the WHOLE result: indexing the builtin's return value element-wise makes the optimizer shrink the load to
+// one dword and splat it)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// plane pairs, smallest terms first
+constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights: f32 [Cout][K] (K = (ty,tx,ci) contiguous)  ->  bf16 planes [3][K/16][Cout][16]
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_weights_kernel(uint2* __restrict__ dst, const float4* __restrict__ w, int Cout, int K) {
+    const int64_t n4 = (int64_t)Cout * (K / 4);
+    const int64_t plane = (int64_t)Cout * K / 4;   // uint2 (4 bf16) units per plane
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int k4 = (int)(i % (K / 4));
+        const int n = (int)(i / (K / 4));
+        const Split4 s = split4(w[i]);
+        const int64_t o = ((int64_t)(k4 >> 2) * Cout + n) * 4 + (k4 & 3);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl * plane + o] = s.p[pl];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward family
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                         const void* __restrict__ wplanes,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ out_scale,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ resid, ideas_conv_params p,
+                                                         int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    static_assert(BM % 64 == 0 && BM * 4 % 256 == 0, "A rows are staged 64 at a time by all 256 threads");
+    constexpr int A_PER = BM * 4 / 256;
+    constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
+    constexpr int BUF = 3 * (PLANE_A + PLANE_B);
+    static_assert(2 * BUF >= BM * 12, "epilogue row table must fit");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+    const int t = threadIdx.x;
+    const int64_t M = (int64_t)p.B * p.OH * p.OW;
+    const int K = p.TY * p.TX * p.Cin;
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n;
+    const int tile_m = swz / tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wplanes, 0, (int)(3u * plane_bytes), (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)in_scale, 0, SCALE ? p.B * p.Cin * 4 : 0, (int)RSRC_FLAGS);
+
+    // ---- per-thread A rows ------------------------------------------------------------------------------------
+    const int kq = t & 3;
+    unsigned a_rowbase[A_PER];   // byte offset of (b, iy0, ix0, ci = 4 kq); arithmetic is mod 2^32, valid taps land < x_bytes
+    unsigned a_inv[A_PER];       // bit tap = 1 -> tap (ty, tx) of this row lies in the zero padding
+    unsigned a_sbase[A_PER];     // byte offset of in_scale[b][4 kq]
+    int a_iyb[A_PER], a_ixb[A_PER], a_img[A_PER];   // REFLECT only
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int r = (t >> 2) + 64 * j;
+        int64_t m = m0 + r;
+        m = m < M ? m : M - 1;                     // rows past M repeat the last row; their results are not stored
+        const int ox = (int)(m % p.OW);
+        const int64_t q = m / p.OW;
+        const int oy = (int)(q % p.OH);
+        const int b = (int)(q / p.OH);
+        const int iyb = oy * p.sy + p.offy, ixb = ox * p.sx + p.offx;
+        a_rowbase[j] = (unsigned)(((b * p.IH + iyb) * p.IW + ixb) * p.Cin + kq * 4) * 4u;
+        a_sbase[j] = (unsigned)(b * p.Cin + kq * 4) * 4u;
+        a_iyb[j] = iyb; a_ixb[j] = ixb; a_img[j] = b * p.IH;
+        unsigned inv = 0;
+        if (!REFLECT) {
+            for (int ty = 0; ty < p.TY; ++ty)
+                for (int tx = 0; tx < p.TX; ++tx) {
+                    const int iy = iyb + ty * p.dy, ix = ixb + tx * p.dx;
+                    const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    inv |= (ok ? 0u : 1u) << (ty * p.TX + tx);
+                }
+        }
+        a_inv[j] = inv;
+    }
+    // B: thread t copies 16 bytes (row t>>1, half t&1) of each plane's contiguous [BN][16] tile
+    const int brow = (t >> 1) % BN;                // BN < 128: the upper threads repeat rows (same value, same address)
+    const unsigned b_voff = (unsigned)(n0 * 32 + brow * 32 + (t & 1) * 16);
+    const int b_lds = 3 * PLANE_A + brow * ROWB + (((t & 1) ^ ((brow >> 3) & 1)) << 4);
+    int a_lds[A_PER];
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int r = (t >> 2) + 64 * j;
+        a_lds[j] = r * ROWB + ((kq * 8) ^ (((r >> 3) & 1) << 4));
+    }
+
+    // block-uniform walk over K = (ty, tx, ci): scalar registers
+    int k_ci = 0, k_tx = 0, k_ty = 0, k_tap = 0;
+
+    // A: two register stages (the loads of tile t+2 are issued before tile t+1 is split, which takes the whole step);
+    // B: one (it is stored to LDS untouched at the top of a step, then immediately re-loaded)
+    struct Stage { float4 a[A_PER], s[A_PER]; };
+    Stage st0, st1;
+    uint4 rb[3];
+    auto gloadA = [&](Stage& st) {
+        const unsigned tapoff = (unsigned)(((k_ty * p.dy) * p.IW + k_tx * p.dx) * p.Cin + k_ci) * 4u;   // uniform
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            unsigned off;
+            if (REFLECT) {
+                const int iy = reflect_coord(a_iyb[j] + k_ty * p.dy, p.IH), ix = reflect_coord(a_ixb[j] + k_tx * p.dx, p.IW);
+                off = (unsigned)(((a_img[j] + iy) * p.IW + ix) * p.Cin + k_ci + kq * 4) * 4u;
+            } else {
+                const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(a_inv[j], k_tap, 1);   // 0 or 0xffffffff
+                off = (a_rowbase[j] + tapoff) | inv;   // (tiles past K: any offset is safe, in range or zero-filled)
+            }
+            st.a[j] = buffer_load4(rx, off, 0);
+            if (SCALE) st.s[j] = buffer_load4(rs_, a_sbase[j], (unsigned)k_ci * 4u);
+        }
+        k_ci += BK;
+        if (k_ci == p.Cin) {
+            k_ci = 0;
+            ++k_tap;
+            if (++k_tx == p.TX) { k_tx = 0; ++k_ty; }
+        }
+    };
+    auto gloadB = [&](int kt) {
+        const unsigned wsoff = (unsigned)kt * (unsigned)p.Cout * 32u;   // uniform
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const float4 v = buffer_load4(rw, b_voff, wsoff + (unsigned)pl * plane_bytes);
+            rb[pl] = make_uint4(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                                __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
+        }
+    };
+    auto lstoreB = [&](int buf) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(base + b_lds + pl * PLANE_B) = rb[pl];
+    };
+    auto lstoreA = [&](int buf, const Stage& st) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            float4 v = st.a[j];
+            // rounded to f32 BEFORE the split (no FMA contraction into the residual), as in the f32 kernel
+            if (SCALE) v = make_float4(mul_rn(v.x, st.s[j].x), mul_rn(v.y, st.s[j].y), mul_rn(v.z, st.s[j].z), mul_rn(v.w, st.s[j].w));
+            const Split4 s = split4(v);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(base + a_lds[j] + pl * PLANE_A) = s.p[pl];
+        }
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int f_swz = (lh ^ ((li >> 3) & 1)) << 4;
+    const int a_off = ((wm * MT) * 32 + li) * ROWB + f_swz;
+    const int b_off = 3 * PLANE_A + ((wn * NT) * 32 + li) * ROWB + f_swz;
+
+    // Pipeline, one barrier per K-step:  step t = { issue loads of tile t+2 -> stage X;  fragments of tile t from
+    // LDS[t&1];  split + store tile t+1 (stage Y, loaded a whole step ago) -> LDS[(t+1)&1];  6*MT*NT MFMAs }.
+    // Tiles beyond K are fetched out of range (zeros) and never consumed: no bounds branch anywhere.
+    auto step = [&](int kt, Stage& ld, const Stage& stg) {
+        const int buf = kt & 1;
+        lstoreB(buf ^ 1);
+        gloadB(kt + 2);
+        gloadA(ld);
+        const unsigned char* base = smem + buf * BUF;
+        bf16x8 fa[MT][3], fb[NT][3];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fa[a][pl] = *reinterpret_cast<const bf16x8*>(base + a_off + pl * PLANE_A + a * 32 * ROWB);
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fb[b][pl] = *reinterpret_cast<const bf16x8*>(base + b_off + pl * PLANE_B + b * 32 * ROWB);
+        lstoreA(buf ^ 1, stg);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb[b][PB[q]], acc[a][b], 0, 0, 0);
+        __syncthreads();
+    };
+    const int nk = K / BK;
+    gloadA(st0);
+    gloadB(0);
+    lstoreA(0, st0);
+    lstoreB(0);
+    gloadA(st1);
+    gloadB(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(kt, st0, st1);       // tile kt+2 -> st0 while tile kt+1 (st1) is split into LDS
+        step(kt + 1, st1, st0);
+    }
+    if (kt < nk) step(kt, st0, st1);
+
+    // ---- epilogue (identical to conv_igemm_kernel) -------------------------------------------------------------
+    int64_t* row_off = reinterpret_cast<int64_t*>(smem);
+    int* row_b = reinterpret_cast<int*>(smem + 8 * BM);
+    if (t < BM) {
+        const int64_t m = m0 + t;
+        int64_t off = -1;
+        int b = 0;
+        if (m < M) {
+            const int ox = (int)(m % p.OW);
+            const int64_t q = m / p.OW;
+            const int oy = (int)(q % p.OH);
+            b = (int)(q / p.OH);
+            off = (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout;
+        }
+        row_off[t] = off;
+        row_b[t] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int n = n0 + (wn * NT + b) * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int64_t off = row_off[row];
+                if (off < 0) continue;
+                float v = mul_rn(acc[a][b][r], p.gain);
+                if (out_scale) v = mul_rn(v, out_scale[(int64_t)row_b[row] * p.Cout + n]);
+                v = mul_then_add(v, 1.0f, bv);
+                if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                if (resid) v = (v + resid[off + n]) * p.resid_gain;
+                if (p.accumulate) y[off + n] += v; else y[off + n] = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_b3_cfg(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
+                  const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    const int64_t tm = ideas_cdiv(M, BM_);
+    const int tn = (int)ideas_cdiv(p->Cout, BN_);
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
+    const unsigned plane_bytes = (unsigned)((int64_t)p->TY * p->TX * p->Cin * p->Cout * 2);
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv_b3_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
+                           dim3((unsigned)(tm * tn)), dim3(256), 0, stream, (float*)y, (const float*)x, wplanes,
+                           in_scale, out_scale, bias, (const float*)resid, *p, tn, x_bytes, plane_bytes);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ideas_b3_conv_supported(const ideas_conv_params* p) {
+    if (!p) return 0;
+    return p->Cin % 16 == 0 && p->TY * p->TX <= 32 && (int64_t)p->B * p->IH * p->IW * p->Cin * 4 < 0xffffffffLL &&
+           (int64_t)p->TY * p->TX * p->Cin * p->Cout * 6 < 0xffffffffLL;
+}
+
+// called by ideas_conv_igemm for dtype IDEAS_F32_B3 once the arguments are validated; `wplanes` comes from
+// ideas_b3_split_weights
+int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
+                 const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    if (p->Cout > 64) return launch_b3_cfg<2, 2, 2, 2>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);  // 128x128
+    if (p->Cout > 32) return launch_b3_cfg<2, 2, 2, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);  // 128x64
+    return launch_b3_cfg<4, 1, 1, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);                    // 128x32
+}
+
+extern "C" int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, void* stream_) {
+    if (!planes || !wmat) return IDEAS_E_NULL;
+    if (Cout <= 0 || K <= 0) return IDEAS_E_SHAPE;
+    if (K % 16 || !ideas_aligned16(planes) || !ideas_aligned16(wmat)) return IDEAS_E_ALIGN;
+    const int64_t n4 = (int64_t)Cout * (K / 4);
+    const int blocks = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint2*)planes,
+                       (const float4*)wmat, Cout, K);
+    return ideas_launch_status();
+}

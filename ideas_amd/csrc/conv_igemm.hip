@@ -579,13 +579,17 @@ int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_s
 extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
                                 const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
                                 void* stream_) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3) return IDEAS_E_UNSUPPORTED;
     if (!y || !x || !wmat) return IDEAS_E_NULL;
     int rc = check_conv(p);
     if (rc) return rc;
     if (p->Cin % 4) return IDEAS_E_ALIGN;
     if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
     hipStream_t stream = (hipStream_t)stream_;
+    if (dtype == IDEAS_F32_B3) {   // wmat = bf16 planes of ideas_b3_split_weights
+        if (!ideas_b3_conv_supported(p)) return IDEAS_E_UNSUPPORTED;
+        return ideas_b3_fwd(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);
+    }
     if (p->Cout > 64) return launch_fwd_cfg<2, 2, 2, 2>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);  // 128x128
     if (p->Cout > 32) return launch_fwd_cfg<2, 2, 2, 1>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);  // 128x64
     return launch_fwd_cfg<4, 1, 1, 1>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);                    // 128x32

@@ -26,6 +26,9 @@ CL = torch.channels_last
 # IDEAS_WINOGRAD=0 falls back to the direct implicit GEMM (A/B measurements, debugging).
 import os as _os
 WINOGRAD = _os.environ.get("IDEAS_WINOGRAD", "1") != "0"
+# Contraction arithmetic of the MFMA convolutions (include/ideas_hip.h): "f32" = f32 matrix instruction, "b3" = exact
+# 3-way bf16 split + six bf16 MFMA products (f32-class error, 2.67x the matrix rate).
+MATH = {"f32": _lib.F32, "b3": _lib.F32_B3}[_os.environ.get("IDEAS_MATH", "b3")]
 
 
 def wino_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
@@ -35,7 +38,9 @@ def wino_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     return torch.stack((w0, (s + w1) * 0.5, (s - w1) * 0.5, w2)).contiguous()
 
 
-def _wino_ok(g: "ConvGeom", cin: int, width: int) -> bool:
+def _wino_ok(g: "ConvGeom", cin: int, width: int, fwd: bool = True) -> bool:
+    if fwd and MATH == _lib.F32_B3 and cin % 16 == 0:
+        return False          # the split-bf16 direct kernel outruns the f32 Winograd kernel
     return WINOGRAD and g.kh == 3 and g.kw == 3 and g.stride == 1 and g.pad == 1 and width % 2 == 0 and cin % 8 == 0
 
 
@@ -70,6 +75,15 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
     w = L.wmat
     if not w.is_contiguous():
         w = w.contiguous()
+    if MATH == _lib.F32_B3 and lib.ideas_b3_conv_supported(C.byref(p)):
+        k = L.TY * L.TX * L.Cin
+        planes = torch.empty(3 * L.Cout * k, device=x.device, dtype=torch.bfloat16)
+        _lib.check(lib.ideas_b3_split_weights(_lib.ptr(planes), _lib.ptr(w), L.Cout, k, _lib.stream_ptr()),
+                   "ideas_b3_split_weights")
+        rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(planes), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                  _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.F32_B3, _lib.stream_ptr())
+        _lib.check(rc, "ideas_conv_igemm[b3]")
+        return
     fn = lib.ideas_conv_igemm if (L.Cin % 4 == 0) else lib.ideas_conv_direct
     rc = fn(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(bias),
             _lib.ptr(resid), C.byref(p), _lib.F32, _lib.stream_ptr())
@@ -153,7 +167,7 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
-    if _wino_ok(g, x.shape[1], x.shape[3]) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
+    if _wino_ok(g, x.shape[1], x.shape[3], fwd=False) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
         b, ci, h, wd = x.shape
         co = gy.shape[1]
         gu = torch.zeros((4, co, 3, ci), device=x.device, dtype=torch.float32)

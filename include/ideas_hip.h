@@ -31,7 +31,12 @@ extern "C" {
 #define IDEAS_ABI_VERSION 1
 
 enum { IDEAS_NCHW = 0, IDEAS_NHWC = 1 };
-enum { IDEAS_F32 = 0 };
+/* `dtype` of the convolution entry points.  Tensors are f32 in HBM for both values.
+ *   IDEAS_F32     contraction on the f32 matrix instruction (v_mfma_f32_32x32x2_f32): an exact fmaf chain.
+ *   IDEAS_F32_B3  operands split exactly into three bf16 planes, six plane-pair products on the bf16 matrix
+ *                 instruction with f32 accumulation (csrc/conv_b3.hip): the same f32 error class at 2.67x the matrix
+ *                 rate.  Shapes the split kernels do not cover (Cin % 16 != 0) run the IDEAS_F32 kernel. */
+enum { IDEAS_F32 = 0, IDEAS_F32_B3 = 1 };
 
 enum {
     IDEAS_OK = 0,
@@ -114,6 +119,15 @@ typedef struct ideas_conv_params {
 
 int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
                      const float* bias, const void* resid, const ideas_conv_params* p, int dtype, void* stream);
+
+/* Split-bf16 ("b3") operand preparation for dtype IDEAS_F32_B3 (csrc/conv_b3.hip).
+ *   ideas_b3_conv_supported  1 if ideas_conv_igemm(..., IDEAS_F32_B3, ...) covers the geometry (Cin % 16 == 0, <= 32 taps,
+ *                            x and the weight planes < 4 GiB: the kernel addresses them with 32-bit buffer offsets).
+ *   ideas_b3_split_weights   wmat f32 [Cout][K] (the same matrix ideas_conv_igemm takes for IDEAS_F32) -> `planes`,
+ *                            3*Cout*K bf16 laid out [3][K/16][Cout][16]; K % 16 == 0.  With IDEAS_F32_B3 the `wmat`
+ *                            argument of ideas_conv_igemm is this buffer.  Activations are split inside the kernel. */
+int ideas_b3_conv_supported(const ideas_conv_params* p);
+int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, void* stream);
 
 /* Weight gradient of the same family:  for every o, tap, ci
  *     gw[o][(ty*TX+tx)*Cin + ci] (+)= sum over (b,oy,ox) of  G(b,oy,ox,o) * X(b, iy, ix, ci)
