@@ -597,7 +597,7 @@ extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const 
 
 extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                                 const ideas_conv_params* p, int dtype, void* stream_) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3) return IDEAS_E_UNSUPPORTED;
     if (!gw || !gy || !x) return IDEAS_E_NULL;
     int rc = check_conv(p);
     if (rc) return rc;
@@ -608,6 +608,7 @@ extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const 
         return IDEAS_E_ALIGN;
     if ((int64_t)p->B * p->OH * p->OW >= 0x7fffffffLL) return IDEAS_E_SHAPE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (dtype == IDEAS_F32_B3 && ideas_b3_wgrad_supported(p)) return ideas_b3_wgrad(gw, gy, x, in_scale, out_scale, p, stream);
     if (p->Cout > 64) return launch_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);  // 128 (o) x 128 (k)
     if (p->Cout > 32) return launch_wgrad_cfg<2, 2, 1, 2>(gw, gy, x, in_scale, out_scale, p, stream);  // 64 x 128
     return launch_wgrad_cfg<1, 4, 1, 1>(gw, gy, x, in_scale, out_scale, p, stream);                    // 32 x 128

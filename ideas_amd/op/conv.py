@@ -96,8 +96,8 @@ def launch_wgrad(gw: torch.Tensor, gy: torch.Tensor, x: torch.Tensor, L: Launch,
     p = _params(L, gain)
     mfma = (L.Cin % 4 == 0) and (L.Cout % 4 == 0)
     fn = lib.ideas_conv_wgrad if mfma else lib.ideas_conv_wgrad_direct
-    rc = fn(_lib.ptr(gw), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(out_scale), C.byref(p), _lib.F32,
-            _lib.stream_ptr())
+    rc = fn(_lib.ptr(gw), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(out_scale), C.byref(p),
+            MATH if mfma else _lib.F32, _lib.stream_ptr())
     _lib.check(rc, "ideas_conv_wgrad" if mfma else "ideas_conv_wgrad_direct")
 
 
@@ -167,7 +167,9 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
-    if _wino_ok(g, x.shape[1], x.shape[3], fwd=False) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
+    L = plan_wgrad(x.shape, gy.shape, g)
+    b3 = MATH == _lib.F32_B3 and bool(_lib.load().ideas_b3_wgrad_supported(C.byref(_params(L, gain))))
+    if not b3 and _wino_ok(g, x.shape[1], x.shape[3], fwd=False) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
         b, ci, h, wd = x.shape
         co = gy.shape[1]
         gu = torch.zeros((4, co, 3, ci), device=x.device, dtype=torch.float32)
@@ -179,7 +181,6 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         half = (gu[1] + gu[2]) * 0.5
         dw = torch.stack((gu[0] + half, (gu[1] - gu[2]) * 0.5, half + gu[3]), dim=2)    # [O, ky, kx, I]
         return dw.permute(0, 3, 1, 2)                                                  # [O, I, 3, 3], OHWI in memory
-    L = plan_wgrad(x.shape, gy.shape, g)
     if (lin is None) != (lout is None):   # the MFMA wgrad kernel takes both per-sample scales or neither
         if lin is None:
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)

@@ -127,6 +127,8 @@ int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_s
  *                            3*Cout*K bf16 laid out [3][K/16][Cout][16]; K % 16 == 0.  With IDEAS_F32_B3 the `wmat`
  *                            argument of ideas_conv_igemm is this buffer.  Activations are split inside the kernel. */
 int ideas_b3_conv_supported(const ideas_conv_params* p);
+int ideas_b3_wgrad_supported(const ideas_conv_params* p);   /* 1 if ideas_conv_wgrad(IDEAS_F32_B3) runs the split kernel; otherwise it
+                                                                runs the IDEAS_F32 kernel (same arguments, same result class) */
 int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, void* stream);
 
 /* Weight gradient of the same family:  for every o, tap, ci
