@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 # forward GFLOP per sample at R=256, full width (measured by hooks on the reference)
 F_E, F_G, F_GS, F_EX, F_DR, F_DC = 16.52, 95.99, 0.21, 0.19, 53.26, 1.00
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md (measured 2495)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 
@@ -63,10 +64,13 @@ def parse():
 
 def roofline_probe(device, batch: int, launches: int):
     """Dominant kernel on its heaviest instance, G.layers.7.conv2: modulated 3x3, 128 -> 128 channels at 256x256
-    (19.33 GFLOP per sample).  With the default dispatch that is conv3x3_wino_kernel<true,false>
-    (1-D Winograd F(2,3): it executes 2/3 of the algorithmic multiplies on the f32 MFMA pipe); with IDEAS_WINOGRAD=0 it is
-    the direct implicit GEMM conv_igemm_kernel<2,2,2,2,true,false,true>.  `achieved` = ALGORITHMIC FLOPs / time, timed
-    with HIP events on the launch stream over `launches` back-to-back launches."""
+    (19.33 GFLOP per sample), timed with HIP events on the launch stream over `launches` back-to-back
+    launches.  `achieved` = ALGORITHMIC f32 FLOPs / time.  Which kernel runs depends on the dispatch:
+      IDEAS_MATH=b3 (default)   conv_b3_kernel<2,2,2,2,true,false>: every f32 product = six bf16 MFMA products, so the
+                                pipe's ceiling for this arithmetic is the dense bf16 peak / 6;
+      IDEAS_MATH=f32            conv3x3_wino_kernel<true,false> (1-D Winograd on the f32 MFMA: executes 2/3 of the
+                                multiplies), or with IDEAS_WINOGRAD=0 the direct conv_igemm_kernel<2,2,2,2,true,false,true>."""
+    from ideas_amd import _lib
     from ideas_amd.op import conv as CV
     from ideas_amd.op.conv_plan import ConvGeom
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -87,30 +91,41 @@ def roofline_probe(device, batch: int, launches: int):
     ms = e0.elapsed_time(e1) / launches
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
+    where = " on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch
+    if CV.MATH == _lib.F32_B3:
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        traffic, traffic_note = _pmc_traffic("conv_b3_kernel", "r01_pmc_b3") if batch == 32 else (None, None)
+        return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
+                "kernel": "conv_b3_kernel<2,2,2,2,true,false> (f32 operands split exactly into 3 bf16 planes; 6 "
+                          "v_mfma_f32_32x32x16_bf16 products per f32 product, f32 accumulate)" + where,
+                "peak_note": "dense bf16 MFMA peak %.0f TFLOP/s / 6 products; the f32 MFMA peak is %.1f" %
+                             (PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS),
+                "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+                "executed_bf16_tflops": round(6 * achieved, 1), "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
     wino = CV.WINOGRAD
-    traffic, traffic_note = _pmc_traffic() if (wino and batch == 32) else (None, None)
+    traffic, traffic_note = _pmc_traffic("wino", "r01_pmc") if (wino and batch == 32) else (None, None)
     kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino
               else "conv_igemm_kernel<2,2,2,2,true,false,true> (direct implicit GEMM)")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
-            "kernel": kernel + " on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch,
-            "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "kernel": kernel + where, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
             "mfma_executed_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.csv;
+def _pmc_traffic(kernel_substr: str, prefix: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<prefix>_*.csv;
     the counters cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 reports half the bytes of a wide
     coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB."""
     import csv
     try:
         vals = {}
-        for name, fn in (("FETCH_SIZE", "r01_pmc_fetch_size.csv"), ("WRITE_SIZE", "r01_pmc_write_size.csv")):
+        for name, fn in (("FETCH_SIZE", prefix + "_fetch_size.csv"), ("WRITE_SIZE", prefix + "_write_size.csv")):
             rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn)))
-                    if r["Counter_Name"] == name and "wino" in r["Kernel_Name"]]
+                    if r["Counter_Name"] == name and kernel_substr in r["Kernel_Name"]]
             vals[name] = sum(rows) / len(rows)
         return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
-            "profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv (separate --pmc passes; FETCH_SIZE x2)"
+            "profiles/%s_fetch_size.csv + %s_write_size.csv (separate --pmc passes; FETCH_SIZE x2)" % (prefix, prefix)
     except Exception:
         return None, None
 
@@ -251,6 +266,11 @@ def main():
         return
 
     n_r1 = sum(1 for i in range(1, a.steps + 1) if i % args.d_reg_every == 0)
+    from ideas_amd import _lib
+    from ideas_amd.op import conv as _CV
+    conv_math = ("f32 tensors; MFMA convs contract an exact 3-way bf16 split of both operands (6 bf16 MFMA products per "
+                 "f32 product, f32 accumulate; f32 error class, tests/test_ops_gpu.py)" if _CV.MATH == _lib.F32_B3
+                 else "f32 MFMA (v_mfma_f32_32x32x2_f32)" + (" + 1-D Winograd F(2,3)" if _CV.WINOGRAD else ""))
     ips = world * a.batch * a.steps / dt
     gflop_img = flop_per_image(not a.literal_second_backward, shared=not a.no_share_forward)
     out = {
@@ -261,9 +281,11 @@ def main():
                                "full-width nets, HIP kernels (BASELINE.json configs[2])" % (a.N, a.image_size, a.image_size, a.batch),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
                    "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
-                   "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off"},
+                   "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off",
+                   "conv_arithmetic": conv_math},
         "step_gflop_per_image": round(gflop_img, 1),
-        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+        "step_tflops": round(ips / world * gflop_img / 1e3, 2),      # algorithmic f32 FLOPs of the step / time, per GPU
+        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),   # ... over the f32 MFMA peak
         "losses": {k: round(float(v), 4) for k, v in losses.items() if v.numel() == 1},
     }
     if a.roofline == "on":

@@ -14,7 +14,8 @@
 //
 // The matrix pipe is then no longer the only limiter: a SIMD issues the split arithmetic through the same VALU port
 // as the MFMAs, so the kernel is built to keep everything else OFF the vector ALU:
-//   * weights are split once per launch by ideas_b3_split_weights into step-major planes [3][K/16][Cout][16] bf16:
+//   * weights are split once per launch by ideas_b3_split_weights into step-major planes [3][K/16][Cout][16] bf16
+//     (K-steps ordered (ci/16, ty, tx): taps innermost, so a pixel neighbourhood is revisited in consecutive steps):
 //     the B tile of a K-step is one contiguous 4 KB block, copied global -> LDS without any arithmetic;
 //   * activations are fetched with raw buffer loads: 32-bit offsets, and padding taps get an out-of-range offset,
 //     for which the hardware returns zeros (no predication, no zero-fill selects);
@@ -35,16 +36,20 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// weights: f32 [Cout][K] (K = (ty,tx,ci) contiguous)  ->  bf16 planes [3][K/16][Cout][16]
+// weights: f32 [Cout][K] (K = (ty,tx,ci) contiguous)  ->  bf16 planes [3][K/16][Cout][16], K-step = (ci/16, ty, tx)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void split_weights_kernel(uint2* __restrict__ dst, const float4* __restrict__ w, int Cout, int K) {
+__global__ __launch_bounds__(256) void split_weights_kernel(uint2* __restrict__ dst, const float4* __restrict__ w, int Cout, int K,
+                                                            int Cin) {
     const int64_t n4 = (int64_t)Cout * (K / 4);
     const int64_t plane = (int64_t)Cout * K / 4;   // uint2 (4 bf16) units per plane
+    const int ntaps = K / Cin;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int k4 = (int)(i % (K / 4));
+        const int k = (int)(i % (K / 4)) * 4;      // k = tap * Cin + ci in the f32 matrix
         const int n = (int)(i / (K / 4));
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int step = (ci >> 4) * ntaps + tap;  // K-steps run over the taps of one 16-channel chunk, then the next chunk
         const Split4 s = split4(w[i]);
-        const int64_t o = ((int64_t)(k4 >> 2) * Cout + n) * 4 + (k4 & 3);
+        const int64_t o = ((int64_t)step * Cout + n) * 4 + ((ci & 15) >> 2);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) dst[pl * plane + o] = s.p[pl];
     }
@@ -148,11 +153,13 @@ __global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, 
             st.a[j] = buffer_load4(rx, off, 0);
             if (SCALE) st.s[j] = buffer_load4(rs_, a_sbase[j], (unsigned)k_ci * 4u);
         }
-        k_ci += BK;
-        if (k_ci == p.Cin) {
-            k_ci = 0;
-            ++k_tap;
-            if (++k_tx == p.TX) { k_tx = 0; ++k_ty; }
+        // K order: all taps of one 16-channel chunk, then the next chunk.  The 9 visits to a pixel neighbourhood are then
+        // 9 consecutive steps (L1/L2 hits) instead of three passes over the image a third of the kernel apart (tap-major
+        // order re-fetched the input from HBM once per ky: rocprofv3 FETCH_SIZE 3.6x the tensor)
+        ++k_tap;
+        if (++k_tx == p.TX) {
+            k_tx = 0;
+            if (++k_ty == p.TY) { k_ty = 0; k_tap = 0; k_ci += BK; }
         }
     };
     auto gloadB = [&](int kt) {
@@ -323,13 +330,13 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
     return launch_b3_cfg<4, 1, 1, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);                    // 128x32
 }
 
-extern "C" int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, void* stream_) {
+extern "C" int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream_) {
     if (!planes || !wmat) return IDEAS_E_NULL;
-    if (Cout <= 0 || K <= 0) return IDEAS_E_SHAPE;
-    if (K % 16 || !ideas_aligned16(planes) || !ideas_aligned16(wmat)) return IDEAS_E_ALIGN;
+    if (Cout <= 0 || K <= 0 || Cin <= 0 || K % Cin) return IDEAS_E_SHAPE;
+    if (Cin % 16 || !ideas_aligned16(planes) || !ideas_aligned16(wmat)) return IDEAS_E_ALIGN;
     const int64_t n4 = (int64_t)Cout * (K / 4);
     const int blocks = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
     hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint2*)planes,
-                       (const float4*)wmat, Cout, K);
+                       (const float4*)wmat, Cout, K, Cin);
     return ideas_launch_status();
 }

@@ -78,7 +78,7 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
     if MATH == _lib.F32_B3 and lib.ideas_b3_conv_supported(C.byref(p)):
         k = L.TY * L.TX * L.Cin
         planes = torch.empty(3 * L.Cout * k, device=x.device, dtype=torch.bfloat16)
-        _lib.check(lib.ideas_b3_split_weights(_lib.ptr(planes), _lib.ptr(w), L.Cout, k, _lib.stream_ptr()),
+        _lib.check(lib.ideas_b3_split_weights(_lib.ptr(planes), _lib.ptr(w), L.Cout, k, L.Cin, _lib.stream_ptr()),
                    "ideas_b3_split_weights")
         rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(planes), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                   _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.F32_B3, _lib.stream_ptr())

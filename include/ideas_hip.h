@@ -124,12 +124,13 @@ int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_s
  *   ideas_b3_conv_supported  1 if ideas_conv_igemm(..., IDEAS_F32_B3, ...) covers the geometry (Cin % 16 == 0, <= 32 taps,
  *                            x and the weight planes < 4 GiB: the kernel addresses them with 32-bit buffer offsets).
  *   ideas_b3_split_weights   wmat f32 [Cout][K] (the same matrix ideas_conv_igemm takes for IDEAS_F32) -> `planes`,
- *                            3*Cout*K bf16 laid out [3][K/16][Cout][16]; K % 16 == 0.  With IDEAS_F32_B3 the `wmat`
+ *                            3*Cout*K bf16 laid out [3][K/16][Cout][16] with the K-steps
+ *                            ordered (ci/16, ty, tx); K = taps*Cin, Cin % 16 == 0.  With IDEAS_F32_B3 the `wmat`
  *                            argument of ideas_conv_igemm is this buffer.  Activations are split inside the kernel. */
 int ideas_b3_conv_supported(const ideas_conv_params* p);
 int ideas_b3_wgrad_supported(const ideas_conv_params* p);   /* 1 if ideas_conv_wgrad(IDEAS_F32_B3) runs the split kernel; otherwise it
                                                                 runs the IDEAS_F32 kernel (same arguments, same result class) */
-int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, void* stream);
+int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream);
 
 /* Weight gradient of the same family:  for every o, tap, ci
  *     gw[o][(ty*TX+tx)*Cin + ci] (+)= sum over (b,oy,ox) of  G(b,oy,ox,o) * X(b, iy, ix, ci)

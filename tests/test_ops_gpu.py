@@ -372,14 +372,16 @@ def test_winograd_kernels_vs_direct_and_oracle(case):
     sd = dev(s.float()) if scaled else None
     dd = dev(d.float()) if scaled else None
     res = {}
+    from ideas_amd import _lib
+    math0 = CV.MATH
     for flag in (True, False):
-        CV.WINOGRAD = flag
+        CV.WINOGRAD, CV.MATH = flag, _lib.F32      # the Winograd kernels are the IDEAS_MATH=f32 dispatch
         try:
             yy = CV.conv_fwd_raw(xd, wd, g, 0.1, lin=sd, lout=dd)
             gw = CV.conv_wgrad_raw(gyd, xd, g, tuple(w.shape), 0.1, lin=sd, lout=dd)
             gx = None if refl else CV.conv_dgrad_raw(gyd, wd, g, (H, W), 0.1, lin=dd, lout=sd)
         finally:
-            CV.WINOGRAD = True
+            CV.WINOGRAD, CV.MATH = True, math0
         res[flag] = (yy, gw, gx)
         assert rel_err(yy, y) < TOL, ("y", flag, case, rel_err(yy, y))
         assert rel_err(gw, gw_ref) < GTOL, ("gw", flag, case, rel_err(gw, gw_ref))
@@ -401,23 +403,29 @@ def test_winograd_full_size_properties():
     x2 = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL)
     w = torch.randn(C, C, 3, 3, device="cuda").contiguous(memory_format=CL)
     gain = 1 / math.sqrt(C * 9)
-    y1, y2 = CV.conv_fwd_raw(x1, w, g, gain), CV.conv_fwd_raw(x2, w, g, gain)
-    y12 = CV.conv_fwd_raw(x1 + 2 * x2, w, g, gain)
-    assert rel_err(y12, y1 + 2 * y2) < 5e-6
-    CV.WINOGRAD = False
+    from ideas_amd import _lib
+    math0 = CV.MATH
+    CV.MATH = _lib.F32
     try:
-        yd = CV.conv_fwd_raw(x1, w, g, gain)
+        y1, y2 = CV.conv_fwd_raw(x1, w, g, gain), CV.conv_fwd_raw(x2, w, g, gain)
+        y12 = CV.conv_fwd_raw(x1 + 2 * x2, w, g, gain)
+        assert rel_err(y12, y1 + 2 * y2) < 5e-6
+        CV.WINOGRAD = False
+        try:
+            yd = CV.conv_fwd_raw(x1, w, g, gain)
+        finally:
+            CV.WINOGRAD = True
+        assert rel_err(y1, yd) < 5e-6
+        gy = torch.randn_like(y1)
+        gx = CV.conv_dgrad_raw(gy, w, g, (R, R), gain)
+        lhs = float((gy.double() * y1.double()).sum())
+        rhs = float((gx.double() * x1.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
+        gw = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)
+        lhs_w = float((gw.double() * w.double()).sum())       # <dL/dw, w> == <gy, conv(x, w)> for a conv linear in w
+        assert abs(lhs_w - lhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
     finally:
-        CV.WINOGRAD = True
-    assert rel_err(y1, yd) < 5e-6
-    gy = torch.randn_like(y1)
-    gx = CV.conv_dgrad_raw(gy, w, g, (R, R), gain)
-    lhs = float((gy.double() * y1.double()).sum())
-    rhs = float((gx.double() * x1.double()).sum())
-    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
-    gw = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)
-    lhs_w = float((gw.double() * w.double()).sum())       # <dL/dw, w> == <gy, conv(x, w)> for a conv linear in w
-    assert abs(lhs_w - lhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3
+        CV.MATH = math0
 
 
 # --------------------------------------------------------------------------------------------- full-size properties
@@ -464,3 +472,114 @@ def test_reflect_fold_is_the_adjoint_of_reflection_pad(shape, pad):
     rc = _lib.load().ideas_reflect_fold(_lib.ptr(out), _lib.ptr(gpd), B, H, W, C, pad, _lib.F32, _lib.stream_ptr())
     assert rc == 0
     assert rel_err(out, ref) < 1e-6
+
+
+# --------------------------------------------------------------------------------------------- split-bf16 contraction
+def test_b3_weight_split_is_exact_and_step_major():
+    """ideas_b3_split_weights: hi + mid + lo reproduces every f32 EXACTLY (incl. tiny / huge magnitudes), each plane is
+    the RNE bf16 of the running residual, and the planes are laid out [3][K/16][Cout][16] (K-step = (ci/16, tap))."""
+    import ctypes as C
+    from ideas_amd import _lib
+    torch.manual_seed(3)
+    co, k = 24, 48
+    w = torch.randn(co, k) * torch.logspace(-30, 30, co).view(co, 1)
+    w[0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-39])          # zero, signed zero, exact, f32 subnormal
+    wd = w.cuda()
+    planes = torch.empty(3 * co * k, device="cuda", dtype=torch.bfloat16)
+    cin = 16                                                      # 3 taps x 16 channels; K-steps ordered (ci/16, tap)
+    _lib.check(_lib.load().ideas_b3_split_weights(_lib.ptr(planes), _lib.ptr(wd), co, k, cin, _lib.stream_ptr()), "split")
+    pl = planes.view(3, k // 16, co, 16).permute(0, 2, 1, 3).reshape(3, co, k).cpu()      # one chunk: step == tap
+    normal = w.abs() > 1e-30                                      # f32 subnormals may flush on the device: excluded
+    normal[0, :2] = True                                          # ... but the zeros are checked
+    hi = w.to(torch.bfloat16)
+    assert torch.equal(pl[0][normal], hi[normal])
+    r1 = w - hi.float()
+    assert torch.equal(pl[1][normal], r1.to(torch.bfloat16)[normal])
+    total = pl[0].double() + pl[1].double() + pl[2].double()
+    assert torch.equal(total[normal], w.double()[normal])
+    assert (total[~normal] - w.double()[~normal]).abs().max() < 1e-37
+
+
+B3_CASES = [
+    # B, Cin, Cout, H, W, k, stride, pad, reflect, scaled
+    (2, 64, 128, 32, 32, 3, 1, 1, False, False), (2, 128, 72, 16, 16, 3, 1, 1, False, True), (2, 32, 32, 33, 33, 3, 2, 0, False, False),
+    (2, 48, 200, 20, 20, 1, 1, 0, False, False), (2, 32, 64, 24, 24, 3, 1, 1, True, False), (1, 512, 512, 8, 8, 3, 1, 1, False, True),
+    (3, 16, 16, 7, 12, 3, 1, 1, False, False), (2, 256, 130, 12, 12, 3, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", B3_CASES)
+def test_b3_kernels_have_the_f32_kernels_error(case):
+    """conv_b3.hip / conv_b3_wgrad.hip against f64 on the same inputs as the f32-MFMA kernels: forward, input gradient
+    and weight gradient stay inside the suite's tolerances AND within 1.5x of the f32 kernels' own error (measured in
+    units of sum|x*w|, the natural scale of a dot product's round-off): the split contraction is f32-class."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd import _lib
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, k, st, pd, refl, scaled = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64) * (torch.rand(B, ci, 1, 1, dtype=torch.float64) * 3 + 0.1)
+    w = torch.randn(co, ci, k, k, dtype=torch.float64)
+    s = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if scaled else None
+    d = (torch.rand(B, co, dtype=torch.float64) + 0.5) if scaled else None
+    gain = 1.0 / math.sqrt(ci * k * k)
+
+    def fwd(xx, ww):
+        xs = xx * s.view(B, ci, 1, 1) if scaled else xx
+        xin = F.pad(xs, [pd] * 4, mode="reflect") if refl else xs
+        yy = F.conv2d(xin, ww * gain, stride=st, padding=0 if refl else pd)
+        return yy * d.view(B, co, 1, 1) if scaled else yy
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = fwd(xr, wr)
+    gy = torch.randn_like(y)
+    gx_ref, gw_ref = torch.autograd.grad(y, (xr, wr), gy)
+    y_scale = fwd(x.abs(), w.abs()).detach()                     # sum |x*w| per output
+    g = ConvGeom(k, k, st, pd, refl)
+    xd, wd, gyd = dev(x.float(), True), dev(w.float(), True), dev(gy.float(), True)
+    sd = dev(s.float()) if scaled else None
+    dd = dev(d.float()) if scaled else None
+    err = {}
+    math0 = CV.MATH
+    for name, mode in (("f32", _lib.F32), ("b3", _lib.F32_B3)):
+        CV.MATH = mode
+        try:
+            yy = CV.conv_fwd_raw(xd, wd, g, gain, lin=sd, lout=dd)
+            gw = CV.conv_wgrad_raw(gyd, xd, g, tuple(w.shape), gain, lin=sd, lout=dd)
+            gx = None if refl else CV.conv_dgrad_raw(gyd, wd, g, (H, W), gain, lin=dd, lout=sd)
+        finally:
+            CV.MATH = math0
+        assert rel_err(yy, y) < TOL, ("y", name, case, rel_err(yy, y))
+        assert rel_err(gw, gw_ref) < GTOL, ("gw", name, case, rel_err(gw, gw_ref))
+        if gx is not None:
+            assert rel_err(gx, gx_ref) < GTOL, ("gx", name, case, rel_err(gx, gx_ref))
+        e = ((yy.double().cpu() - y.detach()).abs() / y_scale)
+        err[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    assert err["b3"][0] < 1e-6, err                              # a few f32 ulps of the dot product's scale
+    assert err["b3"][1] <= 1.5 * err["f32"][1] + 1e-9, err      # rms error: same class as the exact-f32 MFMA kernel
+
+
+def test_b3_dispatch_covers_what_it_claims():
+    """ideas_b3_conv_supported / ideas_b3_wgrad_supported are the single source of truth for the dispatch: shapes they
+    reject run the f32 kernels through the same Python entry points (same results, no error)."""
+    import ctypes as C
+    import ideas_amd.op.conv as CV
+    from ideas_amd import _lib
+    from ideas_amd.op.conv_plan import ConvGeom, plan_fwd
+    lib = _lib.load()
+    g = ConvGeom(3, 3, 1, 1, False)
+    for ci, ok in ((24, 0), (32, 1), (8, 0), (64, 1)):
+        x = torch.randn(2, ci, 8, 8, device="cuda").contiguous(memory_format=CL)
+        w = torch.randn(16, ci, 3, 3, device="cuda").contiguous(memory_format=CL)
+        L = plan_fwd(x.shape, w, g)
+        assert lib.ideas_b3_conv_supported(C.byref(CV._params(L, 1.0))) == ok
+        y = CV.conv_fwd_raw(x, w, g, 0.1)
+        ref = F.conv2d(x.double().cpu(), w.double().cpu() * 0.1, padding=1)
+        assert rel_err(y, ref) < TOL
+    # the f32 weight matrix must not be handed to the b3 entry (wmat is then the bf16 plane buffer): unsupported -> error code
+    x = torch.randn(2, 24, 8, 8, device="cuda").contiguous(memory_format=CL)
+    w = torch.randn(16, 24, 3, 3, device="cuda").contiguous(memory_format=CL)
+    y = torch.empty(2, 16, 8, 8, device="cuda").contiguous(memory_format=CL)
+    L = plan_fwd(x.shape, w, g)
+    rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(L.wmat.contiguous()), None, None, None, None,
+                              C.byref(CV._params(L, 1.0)), _lib.F32_B3, _lib.stream_ptr())
+    assert rc == -3
