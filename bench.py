@@ -104,7 +104,7 @@ def roofline_probe(device, batch: int, launches: int):
                 "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
                 "executed_bf16_tflops": round(6 * achieved, 1), "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
     wino = CV.WINOGRAD
-    traffic, traffic_note = _pmc_traffic("wino", "r01_pmc") if (wino and batch == 32) else (None, None)
+    traffic, traffic_note = _pmc_traffic("wino", "r01a_f32_pmc") if (wino and batch == 32) else (None, None)
     kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino
               else "conv_igemm_kernel<2,2,2,2,true,false,true> (direct implicit GEMM)")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -23,9 +23,10 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-benchmark", action="store_true", help="cudnn.benchmark off: MIOpen immediate mode, no per-shape find")
     a = ap.parse_args()
     dev = torch.device("cuda")
-    torch.backends.cudnn.benchmark = True     # the reference sets this (train.py:327)
+    torch.backends.cudnn.benchmark = not a.no_benchmark     # the reference sets True (train.py:327)
     R = 256
     args = TS.default_args(image_size=R)
     torch.manual_seed(0)
@@ -76,8 +77,10 @@ def main():
                 p.requires_grad_(p.is_floating_point() and not k.endswith("kernel"))
 
     t_w = time.perf_counter()
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         step()
+        torch.cuda.synchronize()
+        print("warm-up step %d done at %.0f s" % (i, time.perf_counter() - t_w), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     t_w = time.perf_counter() - t_w
     t0 = time.perf_counter()
@@ -86,7 +89,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"eager_gpu_images_per_sec": round(B * a.steps / dt, 3), "ms_per_step": round(dt / a.steps * 1e3, 1),
-                      "batch": B, "steps": a.steps, "warmup_s": round(t_w, 1), "channels_last": a.channels_last,
+                      "batch": B, "steps": a.steps, "cudnn_benchmark": not a.no_benchmark, "warmup_s": round(t_w, 1), "channels_last": a.channels_last,
                       "note": "oracle step (no R1, elided 2nd backward, no EMA) on cuda:0, MIOpen convs, torch %s" % torch.__version__,
                       "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
