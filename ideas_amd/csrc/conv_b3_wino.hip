@@ -1,0 +1,341 @@
+// 3x3 / stride-1 / pad-1 convolution: 1-D Winograd F(2,3) along x (conv_wino.hip's algebra) contracted with the
+// exact 3-way bf16 split of b3.hpp (conv_b3.hip's arithmetic), NHWC, f32 in/out.
+//
+//     out[y, 2t  ] = M0 + M1 + M2          M_v[y,t,o] = sum_{ky,ci} U_v[o][ky][ci] * V_v[y+ky-1, t, ci]
+//     out[y, 2t+1] = M1 - M2 - M3          V = (d0-d2, d1+d2, d2-d1, d1-d3),  d_j = x[., 2t-1+j, ci]
+//                                          U = (w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2)
+//
+// The b3 kernels are power-limited (the chip clocks down under the bf16 MFMA stream), so the lever that is left is
+// issuing fewer products: F(2,3) needs 2/3 of the direct kernel's MFMAs AND 2/3 of its operand splits.
+//
+// Block = 256 threads, tile 64 column pairs (128 output pixels) x 64 output channels; wave v owns Winograd component v
+// (its own A planes V_v, its own B planes U_v, four 32x32 accumulators), so the K loop is conv_b3's with 12 operand
+// fetches and 24 MFMAs per wave and step.  K-steps run over (16-channel chunk, ky) with ky innermost.
+//   A: thread (row r, quad kq) fetches the four window columns d0..d3 (buffer loads, padding -> out-of-range offset ->
+//      hardware zeros), forms V0..V3 in f32, splits the 16 values and writes 12 eight-byte groups;
+//   B: the transformed weights arrive pre-split from ideas_b3_wino_split_weights as [4 v][3 planes][step][Cout][16] bf16;
+//      the tile of a step is 12 contiguous 2 KB blocks copied global -> LDS.
+// LDS holds ONE pipeline buffer (24 planes x 2 KB = 48 KB; two would allow a single block per CU): the split of tile t+1
+// is computed into registers while tile t is multiplied, and stored between two barriers.
+// Epilogue: the four components of an output pair live in four different waves; they meet in LDS (two 32-channel halves),
+// then out = inverse transform -> gain / demod / bias / act / residual exactly as conv_wino.hip.
+#include "b3.hpp"
+#include <type_traits>
+
+#ifndef WINO_DB
+#define WINO_DB 0        // 0: one LDS buffer, two barriers per step, two blocks per CU (192-236 TFLOP/s on the big layers);
+                         // 1: two buffers (96 KB), one barrier, ONE block per CU: measured slower (156-200), a single
+                         //    wave per SIMD cannot cover the fetch latencies
+#endif
+
+namespace {
+
+constexpr int WINO_OCC = WINO_DB ? 1 : 2;
+constexpr int NBUF = WINO_DB ? 2 : 1;
+constexpr int WP = 64;            // column pairs per block
+constexpr int WN = 64;            // output channels per block
+constexpr int PLANE = 64 * ROWB;  // bytes of one [64 rows][16 bf16] plane (A and B alike)
+constexpr int XROW = 36;          // floats per row of the exchange buffer (32 + pad: conflict-free float4 reads)
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights: element (n, ky, kx, c) at w[base + n*sn + ky*sky + kx*skx + c*sc]  ->  U planes [4][3][3*C/16][N][16] bf16
+//   forward : n = o, c = i on the OHWI parameter          (sn = 9I, sky = 3I, skx = I, sc = 1, base = 0)
+//   dgrad   : n = i, c = o, taps flipped, same parameter  (sn = 1, sky = -3I, skx = -I, sc = 9I, base = 8I)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restrict__ dst, const float* __restrict__ w, int N, int C,
+                                                                 int64_t sn, int64_t sky, int64_t skx, int64_t sc, int64_t base) {
+    const int64_t total = (int64_t)N * 3 * (C / 4);
+    const int nsteps = 3 * (C / 16);
+    const int64_t plane = (int64_t)nsteps * N * 4;        // uint2 units per (v, plane)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % (C / 4)) * 4;
+        const int ky = (int)((i / (C / 4)) % 3);
+        const int n = (int)(i / (3 * (C / 4)));
+        float wk[3][4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wk[kx][e] = w[base + n * sn + ky * sky + kx * skx + (c + e) * sc];
+        float u[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = wk[0][e] + wk[2][e];
+            u[0][e] = wk[0][e];
+            u[1][e] = (s + wk[1][e]) * 0.5f;
+            u[2][e] = (s - wk[1][e]) * 0.5f;
+            u[3][e] = wk[2][e];
+        }
+        const int step = (c >> 4) * 3 + ky;
+        const int64_t o = ((int64_t)step * N + n) * 4 + ((c & 15) >> 2);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const Split4 s = split4(make_float4(u[v][0], u[v][1], u[v][2], u[v][3]));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[(v * 3 + pl) * plane + o] = s.p[pl];
+        }
+    }
+}
+
+template <bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                              const void* __restrict__ uplanes,
+                                                              const float* __restrict__ in_scale,
+                                                              const float* __restrict__ out_scale,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ resid, ideas_conv_params p,
+                                                              int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 24 * PLANE];   // per buffer: A planes [v*3+pl], B 12 + [v*3+pl]
+    static_assert(24 * PLANE >= 4 * WP * XROW * 4, "exchange buffer must fit");
+
+    const int t = threadIdx.x;
+    const int H = p.IH, W = p.IW, W2 = W >> 1;
+    const int64_t M = (int64_t)p.B * H * W2;
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int64_t m0 = (int64_t)tile_m * WP;
+    const int n0 = tile_n * WN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)uplanes, 0, (int)(12u * plane_bytes), (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)in_scale, 0, SCALE ? p.B * p.Cin * 4 : 0, (int)RSRC_FLAGS);
+
+    // ---- this thread's pair row (staging AND epilogue): r = t >> 2 --------------------------------------------------
+    const int r = t >> 2, kq = t & 3;
+    const bool row_live = m0 + r < M;
+    int pb, py, ptx;
+    {
+        const int64_t m = row_live ? m0 + r : M - 1;     // rows past M repeat the last one; nothing of them is stored
+        ptx = (int)(m % W2);
+        const int64_t q = m / W2;
+        py = (int)(q % H);
+        pb = (int)(q / H);
+    }
+    unsigned colo[4], rowb[3], inv = 0;                  // byte offsets; bit (ky*4+j) of inv = tap in the zero padding
+    bool cok[4], rok[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ix = 2 * ptx - 1 + j;
+        if (REFLECT) { ix = reflect_coord(ix, W); cok[j] = true; }
+        else cok[j] = ix >= 0 && ix < W;
+        colo[j] = (unsigned)(ix * p.Cin) * 4u;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        int iy = py + ky - 1;
+        if (REFLECT) { iy = reflect_coord(iy, H); rok[ky] = true; }
+        else rok[ky] = iy >= 0 && iy < H;
+        rowb[ky] = (unsigned)(((pb * H + iy) * W) * p.Cin + kq * 4) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inv |= ((rok[ky] && cok[j]) ? 0u : 1u) << (ky * 4 + j);
+    }
+    const unsigned sbase = (unsigned)(pb * p.Cin + kq * 4) * 4u;
+    const int a_lds = r * ROWB + ((kq * 8) ^ (((r >> 3) & 1) << 4));
+
+    // ---- B: 6 sixteen-byte pieces per thread: plane vp = (t >> 7) + 2 j, row (t & 127) >> 1, half t & 1 ---------------
+    const int brow = (t & 127) >> 1, bhalf = t & 1;
+    const unsigned b_voff = (unsigned)((n0 + brow) * 32 + bhalf * 16) + (unsigned)(t >> 7) * plane_bytes;
+    const int b_lds = 12 * PLANE + (t >> 7) * PLANE + brow * ROWB + ((bhalf ^ ((brow >> 3) & 1)) << 4);
+
+    int k_ky = 0, k_ci = 0;                              // block-uniform walk, ky innermost
+    struct Stage { float4 d[4], s; };
+    Stage st0, st1;
+    uint4 rb[6];
+    auto gloadA = [&](Stage& st) {
+        const unsigned base = (k_ky == 0 ? rowb[0] : k_ky == 1 ? rowb[1] : rowb[2]) + (unsigned)k_ci * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned off = (base + colo[j]) | (unsigned)__builtin_amdgcn_sbfe(inv, k_ky * 4 + j, 1);
+            st.d[j] = buffer_load4(rx, off, 0);
+        }
+        if (SCALE) st.s = buffer_load4(rs_, sbase, (unsigned)k_ci * 4u);
+        if (++k_ky == 3) { k_ky = 0; k_ci += BK; }
+    };
+    auto gloadB = [&](int step) {
+        const unsigned soff = (unsigned)step * (unsigned)p.Cout * 32u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float4 v = buffer_load4(ru, b_voff + (unsigned)(2 * j) * plane_bytes, soff);
+            rb[j] = make_uint4(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                               __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
+        }
+    };
+    struct Planes { uint2 q[4][3]; };
+    auto transform_split = [&](const Stage& st) {
+        float4 d0 = st.d[0], d1 = st.d[1], d2 = st.d[2], d3 = st.d[3];
+        float4 v[4];
+        v[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+        v[1] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+        v[2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+        v[3] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        Planes pl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 e = v[c];
+            if (SCALE) e = make_float4(mul_rn(e.x, st.s.x), mul_rn(e.y, st.s.y), mul_rn(e.z, st.s.z), mul_rn(e.w, st.s.w));
+            const Split4 s = split4(e);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pl.q[c][q] = s.p[q];
+        }
+        return pl;
+    };
+    auto lstoreA = [&](int buf, const Planes& pl) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(smem + buf * 24 * PLANE + (c * 3 + q) * PLANE + a_lds) = pl.q[c][q];
+    };
+    auto lstoreB = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<uint4*>(smem + buf * 24 * PLANE + b_lds + 2 * j * PLANE) = rb[j];
+    };
+
+    const int lane = t & 63, wv = t >> 6;                // wave wv owns Winograd component wv
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    const int f_off = (wv * 3) * PLANE + li * ROWB + ((lh ^ ((li >> 3) & 1)) << 4);
+
+    // step t: LDS[buf] holds tile t; `stg` holds tile t+1's window, rb its weights; tile t+2's window is fetched into `ld`
+    auto step = [&](int tix, Stage& ld, const Stage& stg) {
+        const int buf = WINO_DB ? (tix & 1) : 0;
+        const unsigned char* base = smem + buf * 24 * PLANE;
+        if (WINO_DB) {
+            lstoreB(buf ^ 1);
+            gloadB(tix + 2);
+        }
+        gloadA(ld);
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[a][pl] = *reinterpret_cast<const bf16x8*>(base + f_off + pl * PLANE + a * 32 * ROWB);
+                fb[a][pl] = *reinterpret_cast<const bf16x8*>(base + 12 * PLANE + f_off + pl * PLANE + a * 32 * ROWB);
+            }
+        const Planes pl = transform_split(stg);
+        if (WINO_DB) lstoreA(buf ^ 1, pl);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb[b][PB[q]], acc[a][b], 0, 0, 0);
+        __syncthreads();                                 // everyone is done reading tile t (and tile t+1 is visible)
+        if (!WINO_DB) {
+            lstoreA(0, pl);
+            lstoreB(0);
+            gloadB(tix + 2);
+            __syncthreads();                             // tile t+1 is visible
+        }
+    };
+    const int nk = 3 * (p.Cin / BK);
+    gloadA(st0);
+    gloadB(0);
+    lstoreA(0, transform_split(st0));
+    lstoreB(0);
+    gloadA(st1);
+    gloadB(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(kt, st0, st1);
+        step(kt + 1, st1, st0);
+    }
+    if (kt < nk) step(kt, st0, st1);
+
+    // ---- epilogue: the four components meet in LDS, inverse transform, fused gain / demod / bias / act / residual -----
+    float* exch = reinterpret_cast<float*>(smem);       // [4 v][64 rows][XROW]
+    const int cg = t & 3;                                // this thread finishes 8 channels of its pair row per half
+    const int64_t opix = row_live ? (((int64_t)pb * H + py) * W + 2 * ptx) * p.Cout : 0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                exch[(wv * WP + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * XROW + li] = acc[a][hb][e];
+        __syncthreads();
+        if (row_live) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int cl = cg * 8 + g * 4;           // channel offset inside the 32-channel half
+                const int n = n0 + hb * 32 + cl;
+                if (n < p.Cout) {
+                    const float4 m0v = *reinterpret_cast<const float4*>(exch + (0 * WP + r) * XROW + cl);
+                    const float4 m1v = *reinterpret_cast<const float4*>(exch + (1 * WP + r) * XROW + cl);
+                    const float4 m2v = *reinterpret_cast<const float4*>(exch + (2 * WP + r) * XROW + cl);
+                    const float4 m3v = *reinterpret_cast<const float4*>(exch + (3 * WP + r) * XROW + cl);
+                    const float mm[4][4] = {{m0v.x, m0v.y, m0v.z, m0v.w}, {m1v.x, m1v.y, m1v.z, m1v.w},
+                                            {m2v.x, m2v.y, m2v.z, m2v.w}, {m3v.x, m3v.y, m3v.z, m3v.w}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.Cout) continue;
+                        const float o2[2] = {(mm[0][e] + mm[1][e]) + mm[2][e], (mm[1][e] - mm[2][e]) - mm[3][e]};
+                        const float os = out_scale ? out_scale[(int64_t)pb * p.Cout + n + e] : 1.f;
+                        const float bvv = bias ? bias[n + e] : 0.f;
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            float v = mul_rn(o2[px], p.gain);
+                            if (out_scale) v = mul_rn(v, os);
+                            v = mul_then_add(v, 1.0f, bvv);
+                            if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                            const int64_t yi = opix + (int64_t)px * p.Cout + n + e;
+                            if (resid) v = (v + resid[yi]) * p.resid_gain;
+                            if (p.accumulate) y[yi] += v; else y[yi] = v;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int ideas_b3_wino_supported(const ideas_conv_params* p) {
+    if (!p) return 0;
+    return p->TY == 3 && p->TX == 3 && p->sy == 1 && p->sx == 1 && p->dy == 1 && p->dx == 1 && p->offy == -1 && p->offx == -1 &&
+           p->OH == p->IH && p->OW == p->IW && p->YH == p->IH && p->YW == p->IW && p->osy == 1 && p->osx == 1 && p->ooy == 0 &&
+           p->oox == 0 && (p->IW & 1) == 0 && p->Cin % 16 == 0 && (!p->reflect || (p->IH >= 2 && p->IW >= 2)) &&
+           (int64_t)p->B * p->IH * p->IW * p->Cin * 4 < 0xffffffffLL && (int64_t)p->Cin * p->Cout * 72 < 0xffffffffLL;
+}
+
+extern "C" int ideas_b3_wino_split_weights(void* planes, const void* w, int N, int C, int64_t sn, int64_t sky, int64_t skx,
+                                           int64_t sc, int64_t base, void* stream_) {
+    if (!planes || !w) return IDEAS_E_NULL;
+    if (N <= 0 || C <= 0) return IDEAS_E_SHAPE;
+    if (C % 16 || !ideas_aligned16(planes)) return IDEAS_E_ALIGN;
+    const int64_t total = (int64_t)N * 3 * (C / 4);
+    const int blocks = (int)(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+    hipLaunchKernelGGL(wino_split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint2*)planes,
+                       (const float*)w, N, C, sn, sky, skx, sc, base);
+    return ideas_launch_status();
+}
+
+// called by ideas_conv3x3_wino for dtype IDEAS_F32_B3 (umat = planes of ideas_b3_wino_split_weights)
+int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* in_scale, const float* out_scale,
+                      const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    const int64_t M = (int64_t)p->B * p->IH * (p->IW / 2);
+    const int64_t tm = ideas_cdiv(M, WP);
+    const int tn = (int)ideas_cdiv(p->Cout, WN);
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
+    const unsigned plane_bytes = (unsigned)((int64_t)3 * p->Cin * p->Cout * 2);     // one (v, plane): 3*Cin/16 steps x Cout x 32 B
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
+                           dim3(256), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale, bias,
+                           (const float*)resid, *p, tn, x_bytes, plane_bytes);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}

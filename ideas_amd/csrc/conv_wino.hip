@@ -414,6 +414,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_wgrad_kernel(float* __res
 extern "C" int ideas_conv3x3_wino(void* y, const void* x, const void* umat, const float* in_scale, const float* out_scale,
                                   const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
                                   void* stream_) {
+    if (dtype == IDEAS_F32_B3) {   // umat = bf16 planes of ideas_b3_wino_split_weights
+        if (!y || !x || !umat || !p) return IDEAS_E_NULL;
+        if (!ideas_b3_wino_supported(p)) return IDEAS_E_UNSUPPORTED;
+        if (!ideas_aligned16(x) || !ideas_aligned16(umat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
+        return ideas_b3_wino_fwd(y, x, umat, in_scale, out_scale, bias, resid, p, (hipStream_t)stream_);
+    }
     if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
     if (!y || !x || !umat || !p) return IDEAS_E_NULL;
     if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;

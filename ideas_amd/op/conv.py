@@ -18,6 +18,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from . import conv_plan
 from .conv_plan import ConvGeom, Launch, convT_out_size, plan_dgrad, plan_fwd, plan_wgrad
 
 CL = torch.channels_last
@@ -44,12 +45,37 @@ def _wino_ok(g: "ConvGeom", cin: int, width: int, fwd: bool = True) -> bool:
     return WINOGRAD and g.kh == 3 and g.kw == 3 and g.stride == 1 and g.pad == 1 and width % 2 == 0 and cin % 8 == 0
 
 
+# Winograd F(2,3) variant of the split-bf16 kernel for the 3x3/s1/p1 layers (csrc/conv_b3_wino.hip); IDEAS_B3_WINO=0 keeps them
+# on the direct split kernel.
+B3_WINO = _os.environ.get("IDEAS_B3_WINO", "1") != "0"
+
+
+def _b3_wino_ok(g: "ConvGeom", cin: int, cout: int, width: int) -> bool:
+    return (MATH == _lib.F32_B3 and B3_WINO and g.kh == 3 and g.kw == 3 and g.stride == 1 and g.pad == 1 and width % 2 == 0
+            and cin % 16 == 0 and cout % 4 == 0)
+
+
+def b3_wino_planes(w: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """Winograd-transformed, split weights of a [O,I,3,3] parameter for ideas_conv3x3_wino(IDEAS_F32_B3): the forward matrix,
+    or (transposed) the flipped one of the input gradient, read straight from the OHWI memory of the parameter."""
+    def make():
+        o, i = w.shape[0], w.shape[1]
+        wm = w.permute(0, 2, 3, 1)
+        wm = wm if wm.is_contiguous() else wm.contiguous()
+        n, c, sn, sky, skx, sc, base = (i, o, 1, -3 * i, -i, 9 * i, 8 * i) if transposed else (o, i, 9 * i, 3 * i, i, 1, 0)
+        pl = torch.empty(12 * n * 3 * c, device=w.device, dtype=torch.bfloat16)
+        _lib.check(_lib.load().ideas_b3_wino_split_weights(_lib.ptr(pl), _lib.ptr(wm), n, c, sn, sky, skx, sc, base,
+                                                            _lib.stream_ptr()), "ideas_b3_wino_split_weights")
+        return pl
+    return conv_plan.cached(w, ("b3wino", transposed), make)
+
+
 def launch_wino(y, x, umat, b, cin, h, w, cout, gain, reflect, in_scale=None, out_scale=None, bias=None, resid=None,
-                act=False, alpha=0.2, act_gain=1.0, resid_gain=1.0) -> None:
+                act=False, alpha=0.2, act_gain=1.0, resid_gain=1.0, dtype=_lib.F32) -> None:
     p = _lib.ConvParams(b, h, w, cin, h, w, cout, h, w, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(reflect), int(act),
                         alpha, act_gain, resid_gain, 0, gain)
     rc = _lib.load().ideas_conv3x3_wino(_lib.ptr(y), _lib.ptr(x), _lib.ptr(umat), _lib.ptr(in_scale), _lib.ptr(out_scale),
-                                        _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.F32, _lib.stream_ptr())
+                                        _lib.ptr(bias), _lib.ptr(resid), C.byref(p), dtype, _lib.stream_ptr())
     _lib.check(rc, "ideas_conv3x3_wino")
 
 
@@ -77,9 +103,13 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
         w = w.contiguous()
     if MATH == _lib.F32_B3 and lib.ideas_b3_conv_supported(C.byref(p)):
         k = L.TY * L.TX * L.Cin
-        planes = torch.empty(3 * L.Cout * k, device=x.device, dtype=torch.bfloat16)
-        _lib.check(lib.ideas_b3_split_weights(_lib.ptr(planes), _lib.ptr(w), L.Cout, k, L.Cin, _lib.stream_ptr()),
-                   "ideas_b3_split_weights")
+
+        def split():
+            pl = torch.empty(3 * L.Cout * k, device=x.device, dtype=torch.bfloat16)
+            _lib.check(lib.ideas_b3_split_weights(_lib.ptr(pl), _lib.ptr(w), L.Cout, k, L.Cin, _lib.stream_ptr()),
+                       "ideas_b3_split_weights")
+            return pl
+        planes = conv_plan.cached(L.wsrc, ("b3",) + L.wkey, split) if L.wsrc is not None else split()
         rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(planes), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                   _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.F32_B3, _lib.stream_ptr())
         _lib.check(rc, "ideas_conv_igemm[b3]")
@@ -111,6 +141,13 @@ def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None,
     x = _nhwc(x)
     if resid is not None:
         resid = _nhwc(resid)
+    if _b3_wino_ok(g, x.shape[1], w.shape[0], x.shape[3]):
+        b, ci, h, wd = x.shape
+        co = w.shape[0]
+        y = torch.empty((b, co, h, wd), device=x.device, dtype=x.dtype, memory_format=CL)
+        launch_wino(y, x, b3_wino_planes(w, False), b, ci, h, wd, co, gain, g.reflect, lin, lout, bias, resid, act=act,
+                    alpha=alpha, act_gain=act_gain, resid_gain=resid_gain, dtype=_lib.F32_B3)
+        return y
     if _wino_ok(g, x.shape[1], x.shape[3]):
         b, ci, h, wd = x.shape
         co = w.shape[0]
@@ -141,6 +178,12 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
             return gx
         like = gxp.new_empty((b, c, in_hw[0], in_hw[1]))
         return torch.ops.aten.reflection_pad2d_backward(gxp.contiguous(), like, [g.pad] * 4)
+    if in_hw == (gy.shape[2], gy.shape[3]) and _b3_wino_ok(g, gy.shape[1], w.shape[1], gy.shape[3]):
+        b, co, h, wd = gy.shape
+        ci = w.shape[1]
+        gx = torch.empty((b, ci, h, wd), device=gy.device, dtype=gy.dtype, memory_format=CL)
+        launch_wino(gx, gy, b3_wino_planes(w, True), b, co, h, wd, ci, gain, False, lin, lout, dtype=_lib.F32_B3)
+        return gx
     if in_hw == (gy.shape[2], gy.shape[3]) and _wino_ok(g, gy.shape[1], gy.shape[3]):
         # dgrad of a 3x3/s1/p1 conv = the same conv with the taps flipped and the channel roles swapped
         b, co, h, wd = gy.shape

@@ -63,7 +63,49 @@ class Launch:
     oox: int = 0
     reflect: int = 0
     wmat: Optional[torch.Tensor] = None      # forward family: [Cout, TY, TX, Cin] contiguous
+    wsrc: Optional[torch.Tensor] = None      # the parameter (view) wmat was derived from, and how: cache key for
+    wkey: Optional[tuple] = None             # further derived forms (split-bf16 planes)
     w_slice: Optional[Tuple[int, int]] = None  # wgrad of a phase: (cy, cx) tap offsets inside the full kernel
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Derived-weight cache.  The networks are applied 2-3 times per iteration with unchanged weights (E on X and on the
+# generated images, G on two code pairs, the discriminators in the D and the G phase), and every application re-derives
+# the same matrices: the phase-sliced / transposed copies for input gradients, the split-bf16 planes.  train_step
+# switches the cache on for the duration of an iteration and clears it after every optimiser step; outside of that
+# (plain op calls, tests) nothing is cached, so in-place weight updates by anyone can never be missed.
+# ---------------------------------------------------------------------------------------------------------------
+_CACHE = None
+
+
+def cache_begin() -> None:
+    global _CACHE
+    _CACHE = {}
+
+
+def cache_clear() -> None:
+    if _CACHE is not None:
+        _CACHE.clear()
+
+
+def cache_end() -> None:
+    global _CACHE
+    _CACHE = None
+
+
+def cached(w: torch.Tensor, key, make):
+    """`make()` memoised on (storage address, shape, key) while the cache is on and `w` is (a view of) a Parameter."""
+    if _CACHE is None:
+        return make()
+    base = w._base if w._base is not None else w
+    if not isinstance(base, torch.nn.Parameter):
+        return make()
+    k = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), key)
+    v = _CACHE.get(k)
+    if v is None:
+        v = make()
+        _CACHE[k] = v
+    return v
 
 
 def w_ohwi(w: torch.Tensor) -> torch.Tensor:
@@ -77,7 +119,7 @@ def plan_fwd(x_shape, w: torch.Tensor, g: ConvGeom) -> Launch:
     oh, ow = g.out_size(ih, iw)
     return Launch(B=b, IH=ih, IW=iw, Cin=ci, YH=oh, YW=ow, Cout=co, OH=oh, OW=ow, TY=g.kh, TX=g.kw,
                   sy=g.stride, sx=g.stride, dy=1, dx=1, offy=-g.pad, offx=-g.pad, reflect=int(g.reflect),
-                  wmat=w_ohwi(w))
+                  wmat=w_ohwi(w), wsrc=w, wkey=("fwd",))
 
 
 def _phase(r: int, p: int, s: int, k: int):
@@ -110,10 +152,10 @@ def plan_dgrad(gy_shape, w: torch.Tensor, g: ConvGeom, in_hw: Tuple[int, int]) -
                 need_zero = True
                 continue
             # wmat[i][(jy, jx, o)] = w[o][i][cy + s*jy][cx + s*jx]
-            wm = w[:, :, cy::s, cx::s].permute(1, 2, 3, 0).contiguous()
+            wm = cached(w, ("dgrad", s, cy, cx), lambda: w[:, :, cy::s, cx::s].permute(1, 2, 3, 0).contiguous())
             launches.append(Launch(B=b, IH=oh, IW=ow, Cin=co, YH=ih, YW=iw, Cout=ci, OH=nqy, OW=nqx, TY=jy, TX=jx,
                                    sy=1, sx=1, dy=-1, dx=-1, offy=ey, offx=ex, osy=s, osx=s, ooy=ry, oox=rx,
-                                   wmat=wm))
+                                   wmat=wm, wsrc=w, wkey=("dgrad", s, cy, cx)))
     return launches, need_zero
 
 

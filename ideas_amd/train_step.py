@@ -30,6 +30,7 @@ import torch
 from torch import optim
 from torch.nn import functional as F
 
+from .op import conv_plan
 from .utils import (Box, accumulate, d_logistic_loss, d_r1_loss, draw_boxes, g_nonsaturating_loss,
                     message_to_tensor, patchify_image, requires_grad, tensor_to_message)
 
@@ -118,8 +119,25 @@ def _params_of(trainer, names) -> List[torch.Tensor]:
     return [p for n in names for p in trainer[n].parameters()]
 
 
+def _step(opt) -> None:
+    """Optimiser step + invalidation of the derived-weight cache (op/conv_plan.py): the fused Adam kernel writes the
+    parameters behind autograd's back, so nothing derived from them may outlive it."""
+    opt.step()
+    conv_plan.cache_clear()
+
+
 def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optional[StepDraws] = None,
                     reducer=None, hook: Optional[Callable] = None) -> Dict[str, torch.Tensor]:
+    """``_train_iteration`` with the derived-weight cache (op/conv_plan.py) switched on for its duration."""
+    conv_plan.cache_begin()
+    try:
+        return _train_iteration(trainer, args, X, iter_idx, draws, reducer, hook)
+    finally:
+        conv_plan.cache_end()
+
+
+def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optional[StepDraws] = None,
+                     reducer=None, hook: Optional[Callable] = None) -> Dict[str, torch.Tensor]:
     """Run one iteration in place on ``trainer``; returns the loss tensors (no host sync).
 
     ``reducer(group_name, params)`` is called after each backward (``'d'``, ``'r1'``, ``'g'``, ``'ex'``) to
@@ -184,7 +202,7 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
     T["d_optim"].zero_grad()
     d_total.backward()
     _sync("d", d_params)
-    T["d_optim"].step()
+    _step(T["d_optim"])
     del fake_pred, real_pred, d_total, hat_X1, hat_X2, hat_X3
 
     # ------------------------------------------------------------------ lazy R1 (train.py:105-129)
@@ -203,7 +221,7 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         T["d_optim"].zero_grad()
         r1.backward()
         _sync("r1", d_params)
-        T["d_optim"].step()
+        _step(T["d_optim"])
         del r1, Xr
 
     # ------------------------------------------------------------------ G phase (train.py:135-216)
@@ -251,9 +269,9 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         torch.autograd.backward(losses["Ex_loss"], inputs=ex_params, retain_graph=True)
         torch.autograd.backward(loss_total, inputs=g_params)
         _sync("g", g_params)
-        T["g_optim"].step()
+        _step(T["g_optim"])
         _sync("ex", ex_params)
-        T["ex_optim"].step()
+        _step(T["ex_optim"])
     else:
         # The reference's literal schedule (train.py:209-216): Loss_total.backward(retain_graph) -> g step ->
         # Loss_Ex.backward() (a second traversal of Ex -> E -> G -> Gstru) -> ex step.  Its second traversal reads the
@@ -268,10 +286,10 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
         T["ex_optim"].zero_grad(set_to_none=True)
         loss_total.backward()
         _sync("g", g_params)
-        T["g_optim"].step()
+        _step(T["g_optim"])
         _set_grads(ex_params, ex_grads)
         _sync("ex", ex_params)
-        T["ex_optim"].step()
+        _step(T["ex_optim"])
 
     # ------------------------------------------------------------------ optional lazy path-length reg (not in IDEAS)
     if args.path_regularize and iter_idx % args.g_reg_every == 0:
@@ -335,7 +353,7 @@ def path_length_step(trainer, args, batch: int, image_size: int, device, Z: Opti
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         reducer("g", all_g)
-    T_["g_optim"].step()
+    _step(T_["g_optim"])
     return {"path_loss": penalty.detach(), "path_length": lengths.mean().detach()}
 
 

@@ -131,6 +131,13 @@ int ideas_b3_conv_supported(const ideas_conv_params* p);
 int ideas_b3_wgrad_supported(const ideas_conv_params* p);   /* 1 if ideas_conv_wgrad(IDEAS_F32_B3) runs the split kernel; otherwise it
                                                                 runs the IDEAS_F32 kernel (same arguments, same result class) */
 int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream);
+/* The same for ideas_conv3x3_wino(IDEAS_F32_B3): Winograd-transformed AND split weights, 12*N*3*C bf16 laid out
+ * [4 v][3 planes][3*C/16 steps][N][16] (step = (c/16)*3 + ky).  Element (n, ky, kx, c) of the 3x3 kernel is read at
+ * w[base + n*sn + ky*sky + kx*skx + c*sc] (floats), so the forward matrix (n = o, c = i) and the flipped / transposed one
+ * of the input gradient (n = i, c = o) both come straight from the OHWI parameter. */
+int ideas_b3_wino_supported(const ideas_conv_params* p);
+int ideas_b3_wino_split_weights(void* planes, const void* w, int N, int C, int64_t sn, int64_t sky, int64_t skx, int64_t sc,
+                                int64_t base, void* stream);
 
 /* Weight gradient of the same family:  for every o, tap, ci
  *     gw[o][(ty*TX+tx)*Cin + ci] (+)= sum over (b,oy,ox) of  G(b,oy,ox,o) * X(b, iy, ix, ci)

@@ -539,23 +539,25 @@ def test_b3_kernels_have_the_f32_kernels_error(case):
     sd = dev(s.float()) if scaled else None
     dd = dev(d.float()) if scaled else None
     err = {}
-    math0 = CV.MATH
-    for name, mode in (("f32", _lib.F32), ("b3", _lib.F32_B3)):
-        CV.MATH = mode
+    math0, wino0 = CV.MATH, CV.B3_WINO
+    # "b3" = direct split kernel, "b3w" = its Winograd F(2,3) variant where the geometry allows (else the same as "b3")
+    for name, mode, b3w in (("f32", _lib.F32, True), ("b3", _lib.F32_B3, False), ("b3w", _lib.F32_B3, True)):
+        CV.MATH, CV.B3_WINO = mode, b3w
         try:
             yy = CV.conv_fwd_raw(xd, wd, g, gain, lin=sd, lout=dd)
             gw = CV.conv_wgrad_raw(gyd, xd, g, tuple(w.shape), gain, lin=sd, lout=dd)
             gx = None if refl else CV.conv_dgrad_raw(gyd, wd, g, (H, W), gain, lin=dd, lout=sd)
         finally:
-            CV.MATH = math0
+            CV.MATH, CV.B3_WINO = math0, wino0
         assert rel_err(yy, y) < TOL, ("y", name, case, rel_err(yy, y))
         assert rel_err(gw, gw_ref) < GTOL, ("gw", name, case, rel_err(gw, gw_ref))
         if gx is not None:
             assert rel_err(gx, gx_ref) < GTOL, ("gx", name, case, rel_err(gx, gx_ref))
         e = ((yy.double().cpu() - y.detach()).abs() / y_scale)
         err[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
-    assert err["b3"][0] < 1e-6, err                              # a few f32 ulps of the dot product's scale
-    assert err["b3"][1] <= 1.5 * err["f32"][1] + 1e-9, err      # rms error: same class as the exact-f32 MFMA kernel
+    for name in ("b3", "b3w"):
+        assert err[name][0] < 1e-6, err                          # a few f32 ulps of the dot product's scale
+        assert err[name][1] <= 1.5 * err["f32"][1] + 1e-9, err  # rms error: same class as the exact-f32 MFMA kernel
 
 
 def test_b3_dispatch_covers_what_it_claims():
