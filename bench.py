@@ -66,8 +66,9 @@ def roofline_probe(device, batch: int, launches: int):
     """Dominant kernel on its heaviest instance, G.layers.7.conv2: modulated 3x3, 128 -> 128 channels at 256x256
     (19.33 GFLOP per sample), timed with HIP events on the launch stream over `launches` back-to-back
     launches.  `achieved` = ALGORITHMIC f32 FLOPs / time.  Which kernel runs depends on the dispatch:
-      IDEAS_MATH=b3 (default)   conv_b3_kernel<2,2,2,2,true,false>: every f32 product = six bf16 MFMA products, so the
-                                pipe's ceiling for this arithmetic is the dense bf16 peak / 6;
+      IDEAS_MATH=b3 (default)   conv_b3_wino_kernel<true,false> (IDEAS_B3_WINO=0: conv_b3_kernel<2,2,2,2,true,false>): every f32
+                                product = six bf16 MFMA products, so the pipe's ceiling for this arithmetic is the dense
+                                bf16 peak / 6 (the Winograd variant issues 2/3 of them; `peak` does not credit that);
       IDEAS_MATH=f32            conv3x3_wino_kernel<true,false> (1-D Winograd on the f32 MFMA: executes 2/3 of the
                                 multiplies), or with IDEAS_WINOGRAD=0 the direct conv_igemm_kernel<2,2,2,2,true,false,true>."""
     from ideas_amd import _lib
@@ -94,15 +95,21 @@ def roofline_probe(device, batch: int, launches: int):
     where = " on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch
     if CV.MATH == _lib.F32_B3:
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-        traffic, traffic_note = _pmc_traffic("conv_b3_kernel", "r01_pmc_b3") if batch == 32 else (None, None)
+        b3w = CV.B3_WINO
+        kname = "conv_b3_wino_kernel" if b3w else "conv_b3_kernel"
+        traffic, traffic_note = _pmc_traffic(kname, "r01_pmc_b3w" if b3w else "r01_pmc_b3") if batch == 32 else (None, None)
+        executed = achieved * (4.0 if b3w else 6.0)       # bf16 MFMA FLOPs issued per algorithmic f32 FLOP
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": "conv_b3_kernel<2,2,2,2,true,false> (f32 operands split exactly into 3 bf16 planes; 6 "
-                          "v_mfma_f32_32x32x16_bf16 products per f32 product, f32 accumulate)" + where,
-                "peak_note": "dense bf16 MFMA peak %.0f TFLOP/s / 6 products; the f32 MFMA peak is %.1f" %
-                             (PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS),
+                "kernel": ("conv_b3_wino_kernel<true,false> (1-D Winograd F(2,3): 2/3 of the products; " if b3w else
+                           "conv_b3_kernel<2,2,2,2,true,false> (") +
+                          "f32 operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 products per f32 "
+                          "product, f32 accumulate)" + where,
+                "peak_note": "dense bf16 MFMA peak %.0f TFLOP/s / 6 plane products per f32 product (Winograd not credited); "
+                             "the f32 MFMA peak is %.1f" % (PEAK_BF16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS),
                 "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
-                "executed_bf16_tflops": round(6 * achieved, 1), "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
+                "executed_bf16_tflops": round(executed, 1), "mfma_executed_frac": round(executed / PEAK_BF16_MFMA_TFLOPS, 4),
+                "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
     wino = CV.WINOGRAD
     traffic, traffic_note = _pmc_traffic("wino", "r01a_f32_pmc") if (wino and batch == 32) else (None, None)
     kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino

@@ -156,11 +156,13 @@ __global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, 
         // K order: all taps of one 16-channel chunk, then the next chunk.  The 9 visits to a pixel neighbourhood are then
         // 9 consecutive steps (L1/L2 hits) instead of three passes over the image a third of the kernel apart (tap-major
         // order re-fetched the input from HBM once per ky: rocprofv3 FETCH_SIZE 3.6x the tensor)
-        ++k_tap;
-        if (++k_tx == p.TX) {
-            k_tx = 0;
-            if (++k_ty == p.TY) { k_ty = 0; k_tap = 0; k_ci += BK; }
-        }
+        // (pure arithmetic: hipcc turns uniform selects back into scalar BRANCHES, which cut the K loop's scheduling region)
+        const int nx = k_tx + 1, gx = 1 - (int)((unsigned)(nx - p.TX) >> 31);   // gx = nx >= TX
+        k_tx = nx - gx * p.TX;
+        const int ny = k_ty + gx, gy = 1 - (int)((unsigned)(ny - p.TY) >> 31);
+        k_ty = ny - gy * p.TY;
+        k_tap = (k_tap + 1) * (1 - gy);
+        k_ci += gy * BK;
     };
     auto gloadB = [&](int kt) {
         const unsigned wsoff = (unsigned)kt * (unsigned)p.Cout * 32u;   // uniform

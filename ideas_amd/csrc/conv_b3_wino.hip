@@ -141,14 +141,19 @@ __global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __re
     Stage st0, st1;
     uint4 rb[6];
     auto gloadA = [&](Stage& st) {
-        const unsigned base = (k_ky == 0 ? rowb[0] : k_ky == 1 ? rowb[1] : rowb[2]) + (unsigned)k_ci * 4u;
+        // rowb[k_ky] by scalar masks (a select on a uniform condition comes back from hipcc as a branch)
+        const unsigned e0 = (unsigned)(k_ky - 1) >> 31, e2 = (unsigned)k_ky >> 1, e1 = 1u - e0 - e2;
+        const unsigned base = ((rowb[0] & (0u - e0)) | (rowb[1] & (0u - e1)) | (rowb[2] & (0u - e2))) + (unsigned)k_ci * 4u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned off = (base + colo[j]) | (unsigned)__builtin_amdgcn_sbfe(inv, k_ky * 4 + j, 1);
             st.d[j] = buffer_load4(rx, off, 0);
         }
         if (SCALE) st.s = buffer_load4(rs_, sbase, (unsigned)k_ci * 4u);
-        if (++k_ky == 3) { k_ky = 0; k_ci += BK; }
+        // (pure arithmetic: hipcc turns uniform selects back into scalar BRANCHES, which cut the K loop's scheduling region)
+        const int wrap = (k_ky + 1) / 3;                  // k_ky in 0..2
+        k_ky = k_ky + 1 - 3 * wrap;
+        k_ci += wrap * BK;
     };
     auto gloadB = [&](int step) {
         const unsigned soff = (unsigned)step * (unsigned)p.Cout * 32u;
