@@ -13,25 +13,18 @@
 // fetches and 24 MFMAs per wave and step.  K-steps run over (16-channel chunk, ky) with ky innermost.
 //   A: thread (row r, quad kq) fetches the four window columns d0..d3 (buffer loads, padding -> out-of-range offset ->
 //      hardware zeros), forms V0..V3 in f32, splits the 16 values and writes 12 eight-byte groups;
-//   B: the transformed weights arrive pre-split from ideas_b3_wino_split_weights as [4 v][3 planes][step][Cout][16] bf16;
-//      the tile of a step is 12 contiguous 2 KB blocks copied global -> LDS.
-// LDS holds ONE pipeline buffer (24 planes x 2 KB = 48 KB; two would allow a single block per CU): the split of tile t+1
-// is computed into registers while tile t is multiplied, and stored between two barriers.
+//   B: the transformed weights arrive pre-split from ideas_b3_wino_split_weights as [4 v][3 planes][step][Cout][16] bf16,
+//      which IS the MFMA operand layout (row = channel, 16 K values contiguous): every wave fetches its six operand
+//      registers for the next step straight from global memory (one coalesced 1 KB buffer load each) -- the weights never
+//      pass through LDS, which halves the LDS write traffic and the operand ds_reads of the first version.
+// LDS: two pipeline buffers of the 12 A planes (2 x 24 KB), one barrier per step.
 // Epilogue: the four components of an output pair live in four different waves; they meet in LDS (two 32-channel halves),
 // then out = inverse transform -> gain / demod / bias / act / residual exactly as conv_wino.hip.
 #include "b3.hpp"
 #include <type_traits>
 
-#ifndef WINO_DB
-#define WINO_DB 0        // 0: one LDS buffer, two barriers per step, two blocks per CU (192-236 TFLOP/s on the big layers);
-                         // 1: two buffers (96 KB), one barrier, ONE block per CU: measured slower (156-200), a single
-                         //    wave per SIMD cannot cover the fetch latencies
-#endif
-
 namespace {
 
-constexpr int WINO_OCC = WINO_DB ? 1 : 2;
-constexpr int NBUF = WINO_DB ? 2 : 1;
 constexpr int WP = 64;            // column pairs per block
 constexpr int WN = 64;            // output channels per block
 constexpr int PLANE = 64 * ROWB;  // bytes of one [64 rows][16 bf16] plane (A and B alike)
@@ -77,15 +70,15 @@ __global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restri
 }
 
 template <bool SCALE, bool REFLECT>
-__global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 3) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                               const void* __restrict__ uplanes,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ out_scale,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ resid, ideas_conv_params p,
                                                               int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 24 * PLANE];   // per buffer: A planes [v*3+pl], B 12 + [v*3+pl]
-    static_assert(24 * PLANE >= 4 * WP * XROW * 4, "exchange buffer must fit");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 12 * PLANE];   // two buffers of the A planes [v*3+pl]
+    static_assert(2 * 12 * PLANE >= 4 * WP * XROW * 4, "exchange buffer must fit");
 
     const int t = threadIdx.x;
     const int H = p.IH, W = p.IW, W2 = W >> 1;
@@ -131,15 +124,9 @@ __global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __re
     const unsigned sbase = (unsigned)(pb * p.Cin + kq * 4) * 4u;
     const int a_lds = r * ROWB + ((kq * 8) ^ (((r >> 3) & 1) << 4));
 
-    // ---- B: 6 sixteen-byte pieces per thread: plane vp = (t >> 7) + 2 j, row (t & 127) >> 1, half t & 1 ---------------
-    const int brow = (t & 127) >> 1, bhalf = t & 1;
-    const unsigned b_voff = (unsigned)((n0 + brow) * 32 + bhalf * 16) + (unsigned)(t >> 7) * plane_bytes;
-    const int b_lds = 12 * PLANE + (t >> 7) * PLANE + brow * ROWB + ((bhalf ^ ((brow >> 3) & 1)) << 4);
-
     int k_ky = 0, k_ci = 0;                              // block-uniform walk, ky innermost
     struct Stage { float4 d[4], s; };
     Stage st0, st1;
-    uint4 rb[6];
     auto gloadA = [&](Stage& st) {
         // rowb[k_ky] by scalar masks (a select on a uniform condition comes back from hipcc as a branch)
         const unsigned e0 = (unsigned)(k_ky - 1) >> 31, e2 = (unsigned)k_ky >> 1, e1 = 1u - e0 - e2;
@@ -154,15 +141,6 @@ __global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __re
         const int wrap = (k_ky + 1) / 3;                  // k_ky in 0..2
         k_ky = k_ky + 1 - 3 * wrap;
         k_ci += wrap * BK;
-    };
-    auto gloadB = [&](int step) {
-        const unsigned soff = (unsigned)step * (unsigned)p.Cout * 32u;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const float4 v = buffer_load4(ru, b_voff + (unsigned)(2 * j) * plane_bytes, soff);
-            rb[j] = make_uint4(__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
-                               __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w));
-        }
     };
     struct Planes { uint2 q[4][3]; };
     auto transform_split = [&](const Stage& st) {
@@ -187,11 +165,7 @@ __global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __re
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(smem + buf * 24 * PLANE + (c * 3 + q) * PLANE + a_lds) = pl.q[c][q];
-    };
-    auto lstoreB = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<uint4*>(smem + buf * 24 * PLANE + b_lds + 2 * j * PLANE) = rb[j];
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(smem + buf * 12 * PLANE + (c * 3 + q) * PLANE + a_lds) = pl.q[c][q];
     };
 
     const int lane = t & 63, wv = t >> 6;                // wave wv owns Winograd component wv
@@ -204,55 +178,55 @@ __global__ __launch_bounds__(256, WINO_OCC) void conv_b3_wino_kernel(float* __re
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     const int f_off = (wv * 3) * PLANE + li * ROWB + ((lh ^ ((li >> 3) & 1)) << 4);
+    // B operand registers of wave wv: planes (wv, pl), channel rows n0 + b*32 + li, K half lh
+    const unsigned fb_voff = (unsigned)((n0 + li) * 32 + lh * 16) + (unsigned)(wv * 3) * plane_bytes;
+    struct BFrag { bf16x8 f[2][3]; };
+    auto gloadB = [&](int stepi, BFrag& fb) {
+        const unsigned soff = (unsigned)stepi * (unsigned)p.Cout * 32u;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fb.f[b][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    ru, (int)(fb_voff + (unsigned)pl * plane_bytes + (unsigned)(b * 32 * 32)), (int)soff, 0));
+    };
 
-    // step t: LDS[buf] holds tile t; `stg` holds tile t+1's window, rb its weights; tile t+2's window is fetched into `ld`
-    auto step = [&](int tix, Stage& ld, const Stage& stg) {
-        const int buf = WINO_DB ? (tix & 1) : 0;
-        const unsigned char* base = smem + buf * 24 * PLANE;
-        if (WINO_DB) {
-            lstoreB(buf ^ 1);
-            gloadB(tix + 2);
-        }
+    // step t: LDS[t&1] holds tile t's A planes, `fbc` its weights; tile t+1's window is in `stg` (split into LDS[(t+1)&1]
+    // during this step), its weights are fetched into `fbn`; tile t+2's window is fetched into `ld`
+    auto step = [&](int tix, Stage& ld, const Stage& stg, const BFrag& fbc, BFrag& fbn) {
+        const int buf = tix & 1;
+        const unsigned char* base = smem + buf * 12 * PLANE;
         gloadA(ld);
-        bf16x8 fa[2][3], fb[2][3];
+        gloadB(tix + 1, fbn);
+        bf16x8 fa[2][3];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < 3; ++pl)
                 fa[a][pl] = *reinterpret_cast<const bf16x8*>(base + f_off + pl * PLANE + a * 32 * ROWB);
-                fb[a][pl] = *reinterpret_cast<const bf16x8*>(base + 12 * PLANE + f_off + pl * PLANE + a * 32 * ROWB);
-            }
-        const Planes pl = transform_split(stg);
-        if (WINO_DB) lstoreA(buf ^ 1, pl);
+        lstoreA(buf ^ 1, transform_split(stg));
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb[b][PB[q]], acc[a][b], 0, 0, 0);
-        __syncthreads();                                 // everyone is done reading tile t (and tile t+1 is visible)
-        if (!WINO_DB) {
-            lstoreA(0, pl);
-            lstoreB(0);
-            gloadB(tix + 2);
-            __syncthreads();                             // tile t+1 is visible
-        }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fbc.f[b][PB[q]], acc[a][b], 0, 0, 0);
+        __syncthreads();
     };
     const int nk = 3 * (p.Cin / BK);
+    BFrag fb0, fb1;
     gloadA(st0);
-    gloadB(0);
+    gloadB(0, fb0);
     lstoreA(0, transform_split(st0));
-    lstoreB(0);
     gloadA(st1);
-    gloadB(1);
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        step(kt, st0, st1);
-        step(kt + 1, st1, st0);
+        step(kt, st0, st1, fb0, fb1);
+        step(kt + 1, st1, st0, fb1, fb0);
     }
-    if (kt < nk) step(kt, st0, st1);
+    if (kt < nk) step(kt, st0, st1, fb0, fb1);
 
     // ---- epilogue: the four components meet in LDS, inverse transform, fused gain / demod / bias / act / residual -----
     float* exch = reinterpret_cast<float*>(smem);       // [4 v][64 rows][XROW]
