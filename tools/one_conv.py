@@ -2,7 +2,7 @@
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ideas_amd.op.conv import conv_fwd_raw
+from ideas_amd.op.conv import conv_fwd_raw, conv_wgrad_raw
 from ideas_amd.op.conv_plan import ConvGeom
 
 ap = argparse.ArgumentParser()
@@ -11,6 +11,7 @@ ap.add_argument("--k", type=int, default=3)
 ap.add_argument("--stride", type=int, default=1)
 ap.add_argument("--mod", type=int, default=1)
 ap.add_argument("--reps", type=int, default=6)
+ap.add_argument("--op", default="fwd", choices=["fwd", "wgrad"])
 a = ap.parse_args()
 b, ci, h, co = map(int, a.shape.split(","))
 x = torch.randn(b, ci, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
@@ -18,13 +19,16 @@ w = torch.randn(co, ci, a.k, a.k, device="cuda").contiguous(memory_format=torch.
 lin = torch.rand(b, ci, device="cuda") + 0.5 if a.mod else None
 lout = torch.rand(b, co, device="cuda") + 0.5 if a.mod else None
 g = ConvGeom(a.k, a.k, a.stride, a.k // 2 if a.stride == 1 else 0, False)
+y = conv_fwd_raw(x, w, g, 0.1, lin, lout)
+gy = torch.randn_like(y)
+run = (lambda: conv_fwd_raw(x, w, g, 0.1, lin, lout)) if a.op == "fwd" else (lambda: conv_wgrad_raw(gy, x, g, w.shape, 0.1, lin, lout))
 for _ in range(a.reps):
-    y = conv_fwd_raw(x, w, g, 0.1, lin, lout)
+    run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.reps):
-    y = conv_fwd_raw(x, w, g, 0.1, lin, lout)
+    run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 oh = y.shape[2]
