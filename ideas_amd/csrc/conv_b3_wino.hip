@@ -21,13 +21,13 @@
 // Epilogue: the four components of an output pair live in four different waves; they meet in LDS (two 32-channel halves),
 // then out = inverse transform -> gain / demod / bias / act / residual exactly as conv_wino.hip.
 #include "b3.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
 
 constexpr int WP = 64;            // column pairs per block
 constexpr int WN = 64;            // output channels per block
-constexpr int PLANE = 64 * ROWB;  // bytes of one [64 rows][16 bf16] plane (A and B alike)
 constexpr int XROW = 36;          // floats per row of the exchange buffer (32 + pad: conflict-free float4 reads)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -69,16 +69,25 @@ __global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restri
     }
 }
 
-template <bool SCALE, bool REFLECT>
-__global__ __launch_bounds__(256, 3) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
+// NH = 1: 256 threads, tile 64 pairs x  64 channels, K-step 16 channels (4 waves  = the 4 Winograd components)
+// NH = 2: 512 threads, tile 64 pairs x 128 channels, K-step 32 channels (8 waves  = 4 components x 2 channel halves):
+//         the same window transform + split now feeds twice the products (3.3 instead of 6.6 vector instructions per
+//         MFMA) and there is one barrier per 48 MFMAs; one block per CU (96 KB LDS), two waves per SIMD.
+template <bool SCALE, bool REFLECT, int NH>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                               const void* __restrict__ uplanes,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ out_scale,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ resid, ideas_conv_params p,
                                                               int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 12 * PLANE];   // two buffers of the A planes [v*3+pl]
-    static_assert(2 * 12 * PLANE >= 4 * WP * XROW * 4, "exchange buffer must fit");
+    constexpr int KS = BK * NH;                 // channels per K-step
+    constexpr int KQ = 4 * NH;                  // float4 quads per row and step
+    constexpr int RB = ROWB * NH;               // bytes per LDS row
+    constexpr int PL = WP * RB;                 // bytes per plane
+    constexpr int BN = WN * NH;                 // channels per block
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 12 * PL];   // two buffers of the A planes [v*3+pl]
+    static_assert(2 * 12 * PL >= NH * 4 * WP * XROW * 4, "exchange buffer must fit");
 
     const int t = threadIdx.x;
     const int H = p.IH, W = p.IW, W2 = W >> 1;
@@ -86,43 +95,44 @@ __global__ __launch_bounds__(256, 3) void conv_b3_wino_kernel(float* __restrict_
     const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
     const int64_t m0 = (int64_t)tile_m * WP;
-    const int n0 = tile_n * WN;
+    const int n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)uplanes, 0, (int)(12u * plane_bytes), (int)RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)in_scale, 0, SCALE ? p.B * p.Cin * 4 : 0, (int)RSRC_FLAGS);
 
-    // ---- this thread's pair row (staging AND epilogue): r = t >> 2 --------------------------------------------------
-    const int r = t >> 2, kq = t & 3;
-    const bool row_live = m0 + r < M;
-    int pb, py, ptx;
+    // ---- staging: thread = (pair row r, channel quad kq of the K-step) --------------------------------------------------
+    const int r = t / KQ, kq = t % KQ;
+    unsigned colo[4], rowb[3], inv = 0, sbase;          // byte offsets; bit (ky*4+j) of inv = tap in the zero padding
     {
-        const int64_t m = row_live ? m0 + r : M - 1;     // rows past M repeat the last one; nothing of them is stored
-        ptx = (int)(m % W2);
+        int64_t m = m0 + r;
+        m = m < M ? m : M - 1;                           // rows past M repeat the last one; nothing of them is stored
+        const int ptx = (int)(m % W2);
         const int64_t q = m / W2;
-        py = (int)(q % H);
-        pb = (int)(q / H);
-    }
-    unsigned colo[4], rowb[3], inv = 0;                  // byte offsets; bit (ky*4+j) of inv = tap in the zero padding
-    bool cok[4], rok[3];
+        const int py = (int)(q % H), pb = (int)(q / H);
+        bool cok[4], rok[3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int ix = 2 * ptx - 1 + j;
-        if (REFLECT) { ix = reflect_coord(ix, W); cok[j] = true; }
-        else cok[j] = ix >= 0 && ix < W;
-        colo[j] = (unsigned)(ix * p.Cin) * 4u;
-    }
+        for (int j = 0; j < 4; ++j) {
+            int ix = 2 * ptx - 1 + j;
+            if (REFLECT) { ix = reflect_coord(ix, W); cok[j] = true; }
+            else cok[j] = ix >= 0 && ix < W;
+            colo[j] = (unsigned)(ix * p.Cin) * 4u;
+        }
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        int iy = py + ky - 1;
-        if (REFLECT) { iy = reflect_coord(iy, H); rok[ky] = true; }
-        else rok[ky] = iy >= 0 && iy < H;
-        rowb[ky] = (unsigned)(((pb * H + iy) * W) * p.Cin + kq * 4) * 4u;
+        for (int ky = 0; ky < 3; ++ky) {
+            int iy = py + ky - 1;
+            if (REFLECT) { iy = reflect_coord(iy, H); rok[ky] = true; }
+            else rok[ky] = iy >= 0 && iy < H;
+            rowb[ky] = (unsigned)(((pb * H + iy) * W) * p.Cin + kq * 4) * 4u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) inv |= ((rok[ky] && cok[j]) ? 0u : 1u) << (ky * 4 + j);
+            for (int j = 0; j < 4; ++j) inv |= ((rok[ky] && cok[j]) ? 0u : 1u) << (ky * 4 + j);
+        }
+        sbase = (unsigned)(pb * p.Cin + kq * 4) * 4u;
     }
-    const unsigned sbase = (unsigned)(pb * p.Cin + kq * 4) * 4u;
-    const int a_lds = r * ROWB + ((kq * 8) ^ (((r >> 3) & 1) << 4));
+    // LDS position of this thread's 8-byte group: 16-byte chunks of a row are XOR-swizzled so that the ds_read_b128 operand
+    // fetch is conflict-free (32-byte rows: chunk ^= row bit 3;  64-byte rows: chunk ^= row bits 2-3)
+    const int a_lds = NH == 1 ? r * RB + ((kq * 8) ^ (((r >> 3) & 1) << 4))
+                              : r * RB + ((((kq >> 1) ^ ((r >> 2) & 3)) << 4) | ((kq & 1) << 3));
 
     int k_ky = 0, k_ci = 0;                              // block-uniform walk, ky innermost
     struct Stage { float4 d[4], s; };
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void conv_b3_wino_kernel(float* __restrict_
         // (pure arithmetic: hipcc turns uniform selects back into scalar BRANCHES, which cut the K loop's scheduling region)
         const int wrap = (k_ky + 1) / 3;                  // k_ky in 0..2
         k_ky = k_ky + 1 - 3 * wrap;
-        k_ci += wrap * BK;
+        k_ci += wrap * KS;
     };
     struct Planes { uint2 q[4][3]; };
     auto transform_split = [&](const Stage& st) {
@@ -165,10 +175,11 @@ __global__ __launch_bounds__(256, 3) void conv_b3_wino_kernel(float* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(smem + buf * 12 * PLANE + (c * 3 + q) * PLANE + a_lds) = pl.q[c][q];
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(smem + buf * 12 * PL + (c * 3 + q) * PL + a_lds) = pl.q[c][q];
     };
 
-    const int lane = t & 63, wv = t >> 6;                // wave wv owns Winograd component wv
+    const int lane = t & 63, wave = t >> 6;
+    const int wv = wave & 3, wh = wave >> 2;             // Winograd component, channel half of this wave
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[2][2];
 #pragma unroll
@@ -177,79 +188,116 @@ __global__ __launch_bounds__(256, 3) void conv_b3_wino_kernel(float* __restrict_
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    const int f_off = (wv * 3) * PLANE + li * ROWB + ((lh ^ ((li >> 3) & 1)) << 4);
-    // B operand registers of wave wv: planes (wv, pl), channel rows n0 + b*32 + li, K half lh
-    const unsigned fb_voff = (unsigned)((n0 + li) * 32 + lh * 16) + (unsigned)(wv * 3) * plane_bytes;
+    const int f_base = (wv * 3) * PL + li * RB;
+    auto f_chunk = [&](int kh) { return NH == 1 ? ((lh ^ ((li >> 3) & 1)) << 4) : (((kh * 2 + lh) ^ ((li >> 2) & 3)) << 4); };
+    // B operand registers of this wave: planes (wv, pl), channel rows n0 + wh*64 + b*32 + li, K half lh of a 16-channel step
+    const unsigned fb_voff = (unsigned)((n0 + wh * 64 + li) * 32 + lh * 16) + (unsigned)(wv * 3) * plane_bytes;
     struct BFrag { bf16x8 f[2][3]; };
-    auto gloadB = [&](int stepi, BFrag& fb) {
-        const unsigned soff = (unsigned)stepi * (unsigned)p.Cout * 32u;
+    int b_ky = 0, b_kh = 0, b_c = 0;                     // uniform walk over the 16-channel weight steps in consumption order
+    auto gloadB = [&](BFrag& fb) {
+        const unsigned soff = (unsigned)(((NH * b_c + b_kh) * 3 + b_ky) * p.Cout) * 32u;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
                 fb.f[b][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                     ru, (int)(fb_voff + (unsigned)pl * plane_bytes + (unsigned)(b * 32 * 32)), (int)soff, 0));
+        const int ch = (b_kh + 1) / NH;                  // carries, pure arithmetic
+        b_kh = b_kh + 1 - NH * ch;
+        const int cy = (b_ky + ch) / 3;
+        b_ky = b_ky + ch - 3 * cy;
+        b_c += cy;
     };
-
-    // step t: LDS[t&1] holds tile t's A planes, `fbc` its weights; tile t+1's window is in `stg` (split into LDS[(t+1)&1]
-    // during this step), its weights are fetched into `fbn`; tile t+2's window is fetched into `ld`
-    auto step = [&](int tix, Stage& ld, const Stage& stg, const BFrag& fbc, BFrag& fbn) {
-        const int buf = tix & 1;
-        const unsigned char* base = smem + buf * 12 * PLANE;
-        gloadA(ld);
-        gloadB(tix + 1, fbn);
-        bf16x8 fa[2][3];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                fa[a][pl] = *reinterpret_cast<const bf16x8*>(base + f_off + pl * PLANE + a * 32 * ROWB);
-        lstoreA(buf ^ 1, transform_split(stg));
+    auto mfmas = [&](const bf16x8 (&fa)[2][3], const BFrag& fb) {
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fbc.f[b][PB[q]], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb.f[b][PB[q]], acc[a][b], 0, 0, 0);
+    };
+    auto afrags = [&](const unsigned char* base, int kh, bf16x8 (&fa)[2][3]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fa[a][pl] = *reinterpret_cast<const bf16x8*>(base + f_base + pl * PL + a * 32 * RB + f_chunk(kh));
+    };
+
+    // step t: LDS[t&1] holds tile t's A planes, `fbc` the weights of its first 16 channels; tile t+1's window is in `stg`
+    // (transformed + split into LDS[(t+1)&1] during this step); tile t+2's window is fetched into `ld`; the weights of
+    // every 16-channel half-step are fetched one half-step ahead
+    auto step = [&](int tix, Stage& ld, const Stage& stg, BFrag& fbc, BFrag& fbn) {
+        const unsigned char* base = smem + (tix & 1) * 12 * PL;
+        gloadA(ld);
+        gloadB(fbn);
+        bf16x8 fa[2][3];
+        afrags(base, 0, fa);
+        lstoreA((tix & 1) ^ 1, transform_split(stg));
+        mfmas(fa, fbc);
+        if (NH == 2) {
+            gloadB(fbc);
+            bf16x8 fa1[2][3];
+            afrags(base, 1, fa1);
+            mfmas(fa1, fbn);
+        }
         __syncthreads();
     };
-    const int nk = 3 * (p.Cin / BK);
+    const int nk = 3 * (p.Cin / KS);
     BFrag fb0, fb1;
     gloadA(st0);
-    gloadB(0, fb0);
+    gloadB(fb0);
     lstoreA(0, transform_split(st0));
     gloadA(st1);
     __syncthreads();
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        step(kt, st0, st1, fb0, fb1);
-        step(kt + 1, st1, st0, fb1, fb0);
+    if (NH == 2) {                                       // both weight buffers return to their roles every step
+        for (; kt + 1 < nk; kt += 2) {
+            step(kt, st0, st1, fb0, fb1);
+            step(kt + 1, st1, st0, fb0, fb1);
+        }
+        if (kt < nk) step(kt, st0, st1, fb0, fb1);
+    } else {
+        for (; kt + 1 < nk; kt += 2) {
+            step(kt, st0, st1, fb0, fb1);
+            step(kt + 1, st1, st0, fb1, fb0);
+        }
+        if (kt < nk) step(kt, st0, st1, fb0, fb1);
     }
-    if (kt < nk) step(kt, st0, st1, fb0, fb1);
 
     // ---- epilogue: the four components meet in LDS, inverse transform, fused gain / demod / bias / act / residual -----
-    float* exch = reinterpret_cast<float*>(smem);       // [4 v][64 rows][XROW]
-    const int cg = t & 3;                                // this thread finishes 8 channels of its pair row per half
-    const int64_t opix = row_live ? (((int64_t)pb * H + py) * W + 2 * ptx) * p.Cout : 0;
+    float* exch = reinterpret_cast<float*>(smem);       // [NH halves][4 v][64 rows][XROW]
+    const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;   // this thread finishes 8 channels of pair row er, half eh
+    const bool row_live = m0 + er < M;
+    int pb = 0;
+    int64_t opix = 0;
+    if (row_live) {
+        const int64_t m = m0 + er;
+        const int ptx = (int)(m % W2);
+        const int64_t q = m / W2;
+        pb = (int)(q / H);
+        opix = ((q * W) + 2 * ptx) * p.Cout;             // q = b*H + y
+    }
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                exch[(wv * WP + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * XROW + li] = acc[a][hb][e];
+                exch[((wh * 4 + wv) * WP + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * XROW + li] = acc[a][hb][e];
         __syncthreads();
         if (row_live) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const int cl = cg * 8 + g * 4;           // channel offset inside the 32-channel half
-                const int n = n0 + hb * 32 + cl;
+                const int cl = cg * 8 + g * 4;           // channel offset inside the 32-channel slice
+                const int n = n0 + eh * 64 + hb * 32 + cl;
                 if (n < p.Cout) {
-                    const float4 m0v = *reinterpret_cast<const float4*>(exch + (0 * WP + r) * XROW + cl);
-                    const float4 m1v = *reinterpret_cast<const float4*>(exch + (1 * WP + r) * XROW + cl);
-                    const float4 m2v = *reinterpret_cast<const float4*>(exch + (2 * WP + r) * XROW + cl);
-                    const float4 m3v = *reinterpret_cast<const float4*>(exch + (3 * WP + r) * XROW + cl);
+                    const float* ex = exch + (eh * 4 * WP + er) * XROW + cl;
+                    const float4 m0v = *reinterpret_cast<const float4*>(ex + 0 * WP * XROW);
+                    const float4 m1v = *reinterpret_cast<const float4*>(ex + 1 * WP * XROW);
+                    const float4 m2v = *reinterpret_cast<const float4*>(ex + 2 * WP * XROW);
+                    const float4 m3v = *reinterpret_cast<const float4*>(ex + 3 * WP * XROW);
                     const float mm[4][4] = {{m0v.x, m0v.y, m0v.z, m0v.w}, {m1v.x, m1v.y, m1v.z, m1v.w},
                                             {m2v.x, m2v.y, m2v.z, m2v.w}, {m3v.x, m3v.y, m3v.z, m3v.w}};
 #pragma unroll
@@ -303,14 +351,21 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
                       const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
     const int64_t M = (int64_t)p->B * p->IH * (p->IW / 2);
     const int64_t tm = ideas_cdiv(M, WP);
-    const int tn = (int)ideas_cdiv(p->Cout, WN);
+    static const bool force4 = getenv("IDEAS_B3_WINO8") && getenv("IDEAS_B3_WINO8")[0] == '0';   // A/B measurements only
+    const bool wide = p->Cin % 32 == 0 && p->Cout > 64 && !force4;     // 8-wave 64 x 128 tile, K-step 32
+    const int tn = (int)ideas_cdiv(p->Cout, wide ? 2 * WN : WN);
     if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
     const unsigned plane_bytes = (unsigned)((int64_t)3 * p->Cin * p->Cout * 2);     // one (v, plane): 3*Cin/16 steps x Cout x 32 B
     auto go = [&](auto sc, auto rf) {
-        hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
-                           dim3(256), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale, bias,
-                           (const float*)resid, *p, tn, x_bytes, plane_bytes);
+        if (wide)
+            hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value, 2>), dim3((unsigned)(tm * tn)),
+                               dim3(512), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale, bias,
+                               (const float*)resid, *p, tn, x_bytes, plane_bytes);
+        else
+            hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value, 1>), dim3((unsigned)(tm * tn)),
+                               dim3(256), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale, bias,
+                               (const float*)resid, *p, tn, x_bytes, plane_bytes);
     };
     using T = std::true_type;
     using F = std::false_type;
