@@ -202,8 +202,10 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
     return gx
 
 
-def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None):
-    """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy."""
+def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None, out=None):
+    """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy.
+    ``out`` (an OHWI-contiguous tensor of that shape): ADD the gradient to it instead of returning a new tensor — the
+    split-K kernels accumulate with atomics anyway, so this costs neither a zero-fill nor an add pass."""
     gy, x = _nhwc(gy), _nhwc(x)
     if (lin is None) != (lout is None):   # the MFMA wgrad kernels take both per-sample scales or neither
         if lin is None:
@@ -223,15 +225,82 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         _lib.check(rc, "ideas_conv3x3_wino_wgrad")
         half = (gu[1] + gu[2]) * 0.5
         dw = torch.stack((gu[0] + half, (gu[1] - gu[2]) * 0.5, half + gu[3]), dim=2)    # [O, ky, kx, I]
-        return dw.permute(0, 3, 1, 2)                                                  # [O, I, 3, 3], OHWI in memory
+        dw = dw.permute(0, 3, 1, 2)                                                    # [O, I, 3, 3], OHWI in memory
+        return dw if out is None else out.add_(dw)
     if (lin is None) != (lout is None):   # the MFMA wgrad kernel takes both per-sample scales or neither
         if lin is None:
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
+    mfma = (L.Cin % 4 == 0) and (L.Cout % 4 == 0)       # the atomics-accumulating kernels
+    if out is not None and mfma and tuple(out.shape) == tuple(w_shape) and out.is_contiguous(memory_format=CL):
+        launch_wgrad(out, gy, x, L, gain, lin, lout)
+        return out
     gw = torch.empty(tuple(w_shape), device=x.device, dtype=torch.float32, memory_format=CL).zero_()
     launch_wgrad(gw, gy, x, L, gain, lin, lout)
-    return gw
+    return gw if out is None else out.add_(gw)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Gradient sink.  Inside ``with grad_sink(params):`` the weight gradients of those parameters are produced on a side
+# stream and accumulated straight into their (pre-existing, e.g. flat-bucket) ``.grad`` — the Functions return None
+# for the weight, so autograd neither allocates, zero-fills nor adds.  The weight-gradient kernels (MFMA-bound) then
+# overlap the HBM-bound elementwise backward passes of the following layers on the main stream.  Leaving the context
+# joins the side stream.  Only plain backward passes qualify (no create_graph), and only parameters named by the caller:
+# a Function cannot see the ``inputs=`` filter of ``torch.autograd.backward``.
+# ----------------------------------------------------------------------------------------------------
+_SINK = {"ids": None, "stream": None}
+
+
+class grad_sink:
+    def __init__(self, params):
+        self.ids = {id(p) for p in params if p.grad is not None and p.is_cuda}
+
+    def __enter__(self):
+        if not self.ids:            # nothing to sink (no pre-existing device gradients): plain autograd
+            return self
+        if _SINK["stream"] is None:
+            _SINK["stream"] = torch.cuda.Stream()
+        _SINK["ids"] = self.ids
+        return self
+
+    def __exit__(self, *exc):
+        if _SINK["ids"] is not None:
+            _SINK["ids"] = None
+            torch.cuda.current_stream().wait_stream(_SINK["stream"])
+
+
+def _sink_target(w: torch.Tensor):
+    ids = _SINK["ids"]
+    if ids is None or torch.is_grad_enabled():
+        return None
+    base = w._base if w._base is not None else w
+    if id(base) not in ids:
+        return None
+    gr = base.grad
+    if gr is None or gr.shape != base.shape or gr.stride() != base.stride():
+        return None
+    if base is w:
+        return gr
+    if w.numel() != base.numel() or w.data_ptr() != base.data_ptr():
+        return None
+    return gr.as_strided(w.shape, w.stride())
+
+
+def weight_grad(w: torch.Tensor, compute, *uses):
+    """``compute(out)`` -> the gradient of ``w`` (added to ``out`` when that is not None).  Returns it, or None after
+    sinking it into ``w.grad`` on the side stream (``uses``: the tensors the kernels read, for the allocator)."""
+    tgt = _sink_target(w)
+    if tgt is None:
+        return compute(None)
+    side, cur = _SINK["stream"], torch.cuda.current_stream()
+    side.wait_stream(cur)
+    for t in uses:
+        if t is not None:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        compute(tgt)
+    return None
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -255,8 +324,16 @@ class _Conv(Function):
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(gy, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
         if ctx.needs_input_grad[1]:
-            gw = _ConvWgrad.apply(gy, x, ctx.g, ctx.gain, tuple(w.shape))
+            gw = _wgrad(w, gy, x, ctx.g, ctx.gain)
         return gx, gw, None, None
+
+
+def _wgrad(w, gy, x, g: ConvGeom, gain: float):
+    """Weight gradient of a dense conv: differentiable Function normally, sunk into w.grad inside grad_sink."""
+    if _sink_target(w) is None:
+        return _ConvWgrad.apply(gy, x, g, gain, tuple(w.shape))
+    gy, x = _nhwc(gy), _nhwc(x)
+    return weight_grad(w, lambda out: conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, out=out), gy, x)
 
 
 class _ConvDgrad(Function):
@@ -276,7 +353,7 @@ class _ConvDgrad(Function):
         if ctx.needs_input_grad[0]:
             g_gy = _Conv.apply(ggx, w, ctx.g, ctx.gain)
         if ctx.needs_input_grad[1]:
-            g_w = _ConvWgrad.apply(gy, ggx, ctx.g, ctx.gain, tuple(w.shape))
+            g_w = _wgrad(w, gy, ggx, ctx.g, ctx.gain)
         return g_gy, g_w, None, None, None
 
 
@@ -334,7 +411,7 @@ class _ConvBiasAct(Function):
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(g_pre, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
         if ctx.needs_input_grad[1]:
-            gw = _ConvWgrad.apply(g_pre, x, ctx.g, ctx.gain, tuple(w.shape))
+            gw = _wgrad(w, g_pre, x, ctx.g, ctx.gain)
         return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None
 
 
@@ -370,7 +447,7 @@ class _ConvT(Function):
         if ctx.needs_input_grad[0]:
             gx = _Conv.apply(gy, w, ctx.g, ctx.gain)
         if ctx.needs_input_grad[1]:
-            gw = _ConvWgrad.apply(x, gy, ctx.g, ctx.gain, tuple(w.shape))
+            gw = _wgrad(w, x, gy, ctx.g, ctx.gain)
         return gx, gw, None, None
 
 

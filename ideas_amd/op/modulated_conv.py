@@ -21,7 +21,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, _nhwc
+from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, weight_grad, _nhwc
 from .conv_plan import ConvGeom, convT_out_size
 from .upfirdn2d import upfirdn2d
 from .fused_act import fused_leaky_relu
@@ -96,9 +96,14 @@ class _ModConv(Function):
         if need_w:
             if ctx.up:
                 wt_shape = (w.shape[1], w.shape[0], w.shape[2], w.shape[3])
-                gw = conv_wgrad_raw(x, gy, g, wt_shape, gain, lin=d, lout=s).transpose(0, 1)
+
+                def up_grad(out):
+                    gwt = conv_wgrad_raw(x, gy, g, wt_shape, gain, lin=d, lout=s).transpose(0, 1)
+                    return gwt if out is None else out.add_(gwt)
+                gw = weight_grad(w, up_grad, x, gy, s, d)
             else:
-                gw = conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, lin=s, lout=d)
+                gw = weight_grad(w, lambda out: conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out),
+                                 x, gy, s, d)
         if need_s:
             # gx = s * (dL/d(s*x)); <x, gx> / s = <x, dL/d(s*x)>
             dot = pixel_dot(x, gx)
@@ -148,7 +153,8 @@ class _ModConvAct(Function):
         if need_x or need_s:
             gx = conv_dgrad_raw(gpre, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
         if need_w:
-            gw = conv_wgrad_raw(gpre, x, g, tuple(w.shape), gain, lin=s, lout=d)
+            gw = weight_grad(w, lambda out: conv_wgrad_raw(gpre, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out),
+                             gpre, x, s, d)
         if need_s:
             ds = pixel_dot(x, gx)
             gs = torch.where(s != 0, ds / s, torch.zeros_like(ds))

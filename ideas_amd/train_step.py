@@ -31,6 +31,7 @@ from torch import optim
 from torch.nn import functional as F
 
 from .op import conv_plan
+from .op.conv import grad_sink
 from .utils import (Box, accumulate, d_logistic_loss, d_r1_loss, draw_boxes, g_nonsaturating_loss,
                     message_to_tensor, patchify_image, requires_grad, tensor_to_message)
 
@@ -200,7 +201,8 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     losses["D_dist_loss"] = d_logistic_loss(T["Ddist"](T2), T["Ddist"](T1))
     d_total = d_total + losses["D_dist_loss"]
     T["d_optim"].zero_grad()
-    d_total.backward()
+    with grad_sink(d_params):
+        d_total.backward()
     _sync("d", d_params)
     _step(T["d_optim"])
     del fake_pred, real_pred, d_total, hat_X1, hat_X2, hat_X3
@@ -219,7 +221,8 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         losses["D_dist_r1_loss"] = d_r1_loss(T["Ddist"](T2r), T2r)
         r1 = r1 + args.dist_r1 / 3 * losses["D_dist_r1_loss"] * args.d_reg_every
         T["d_optim"].zero_grad()
-        r1.backward()
+        with grad_sink(d_params):
+            r1.backward()
         _sync("r1", d_params)
         _step(T["d_optim"])
         del r1, Xr
@@ -266,8 +269,10 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         # optimisers' gradient buffers (flat buckets when the fused optimiser / DDP reducer own them)
         T["ex_optim"].zero_grad()
         T["g_optim"].zero_grad()
-        torch.autograd.backward(losses["Ex_loss"], inputs=ex_params, retain_graph=True)
-        torch.autograd.backward(loss_total, inputs=g_params)
+        with grad_sink(ex_params):
+            torch.autograd.backward(losses["Ex_loss"], inputs=ex_params, retain_graph=True)
+        with grad_sink(g_params):
+            torch.autograd.backward(loss_total, inputs=g_params)
         _sync("g", g_params)
         _step(T["g_optim"])
         _sync("ex", ex_params)
