@@ -585,3 +585,35 @@ def test_b3_dispatch_covers_what_it_claims():
     rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(L.wmat.contiguous()), None, None, None, None,
                               C.byref(CV._params(L, 1.0)), _lib.F32_B3, _lib.stream_ptr())
     assert rc == -3
+
+
+def test_grad_sink_matches_plain_autograd(ops):
+    """op.conv.grad_sink: weight gradients produced on the side stream and accumulated straight into pre-existing .grad
+    buffers equal the ones autograd returns, for listed parameters only, and accumulate across two backward passes."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op import modulated_conv as MC
+    torch.manual_seed(11)
+    B, C, R = 2, 32, 16
+    x = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL)
+    params = [torch.nn.Parameter(torch.randn(64, C, 3, 3, device="cuda").contiguous(memory_format=CL)),    # conv + bias + act
+              torch.nn.Parameter(torch.randn(64, device="cuda") * 0.1),
+              torch.nn.Parameter(torch.randn(48, 64, 3, 3, device="cuda").contiguous(memory_format=CL)),   # stride-2 conv
+              torch.nn.Parameter(torch.randn(48, 40, 3, 3, device="cuda").contiguous(memory_format=CL)),   # transposed conv [I,O,..]
+              torch.nn.Parameter(torch.randn(8, 40, 1, 1, device="cuda").contiguous(memory_format=CL))]    # not listed in the sink
+
+    def loss():
+        h = ops.conv2d_bias_act(x, params[0], params[1], padding=1, gain=0.05)
+        h = ops.conv2d(h, params[2], stride=2, padding=1, gain=0.05)
+        h = ops.conv_transpose2d(h, params[3], stride=2, gain=0.05)
+        h = ops.conv2d(h, params[4], gain=0.1)
+        return (h * h).mean()
+    ref = torch.autograd.grad(loss(), params)
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    with CV.grad_sink(params[:4]):
+        loss().backward()
+    with CV.grad_sink(params[:4]):
+        loss().backward()
+    torch.cuda.synchronize()
+    for p, g in zip(params, ref):
+        assert rel_err(p.grad, 2 * g) < 2e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))
