@@ -202,6 +202,14 @@ int ideas_reflect_fold(void* gx, const void* gpadded, int B, int H, int W, int C
 int ideas_adam_ema(float* p, const float* g, float* v, float* ema, int64_t n, float lr, float beta2, float eps,
                    float bias_correction2, float ema_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input pipeline (dataset.py:10-85 + the transform of train.py:443-449), device side.
+ * x_u8: decoded images, uint8 [B][H][W][C] (PIL's HWC order).  y: f32 [B][H][W][C] = the NHWC activation layout.
+ *   y = ((x / 255) - mean) / stdv           -- ToTensor then Normalize(mean, stdv), the same two roundings
+ * flip_u8 (optional, uint8 [B]): non-zero -> that sample is mirrored horizontally (RandomHorizontalFlip; the caller draws). */
+int ideas_image_u8_to_f32(float* y, const void* x_u8, const void* flip_u8, int B, int H, int W, int C, float mean, float stdv,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
