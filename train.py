@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Training entry point: the reference's ``train.py`` (``__main__`` at :325-476, loop at :21-322) on the MI355X path.
+
+Same flags, same log lines, same checkpoint format; one process per GPU:
+
+    python train.py --exp_name e0 --dataset_path /data/ffhq --dataset_type normal --num_iters 80000 --batch_size 32
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ... (batch_size is per GPU)
+
+What differs from the reference: the data loader hands uint8 images to the device and the transform runs
+there (ideas_amd/data.py); gradients are averaged across ranks by one RCCL all-reduce per optimiser group (ideas_amd/ddp.py);
+Adam + EMA are one fused launch per group (ideas_amd/optim.py); sample grids are not written (torchvision is not a
+dependency) -- the test line with ACC / L1 is.  Below 256x256 the co-occurrence discriminator cannot run (models.py:400);
+``--no_dco`` trains without its terms, which is only meant for smoke runs.
+"""
+import argparse
+import os
+import random
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def time_change(t: float) -> str:
+    """utils.py: h/m/s formatting of the log line."""
+    t = int(t)
+    return f"{t // 3600:d}h{(t % 3600) // 60:02d}m{t % 60:02d}s"
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--exp_name", type=str, required=True)
+    p.add_argument("--dataset_path", type=str, required=True)
+    p.add_argument("--dataset_type", choices=['lmdb', 'normal'], required=True)
+    p.add_argument("--num_iters", type=int, required=True)
+    p.add_argument("--N", type=int, default=1)
+    p.add_argument("--lambda_Ex", type=float, default=10)
+    p.add_argument("--ckpt", type=str, default=None)
+    p.add_argument("--lr", type=float, default=0.002)
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--image_size", type=int, default=256)
+    p.add_argument("--real_r1", type=float, default=10)
+    p.add_argument("--texture_r1", type=float, default=1)
+    p.add_argument("--dist_r1", type=float, default=1)
+    p.add_argument("--ref_crop", type=int, default=4)
+    p.add_argument("--n_crop", type=int, default=8)
+    p.add_argument("--d_reg_every", type=int, default=16)
+    p.add_argument("--channel", type=int, default=32)
+    p.add_argument("--channel_multiplier", type=int, default=1)
+    p.add_argument("--structure_channel", type=int, default=8)
+    p.add_argument("--texture_channel", type=int, default=2048)
+    p.add_argument("--log_every", type=int, default=200)
+    p.add_argument("--show_every", type=int, default=1000)
+    p.add_argument("--save_every", type=int, default=200000)
+    # additions of this build
+    p.add_argument("--no_dco", action="store_true", help="drop the co-occurrence discriminator terms (image_size < 256)")
+    p.add_argument("--num_workers", type=int, default=4)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--path_regularize", type=float, default=0.0, help="stylegan2/train.py's lazy path-length weight (off in IDEAS)")
+    args = p.parse_args()
+    args.start_iter = 0
+    args.blur_kernel = (1, 3, 3, 1)
+    args.use_dco = not args.no_dco
+    args.elide_second_backward, args.share_forward = True, True
+    args.g_reg_every, args.path_batch_shrink = 4, 2
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py needs an MI355X: the product path has no CPU fallback")
+    if os.environ.get("IDEAS_BENCH_SHARE_GPU") == "1":     # test affordance: several ranks on a 1-GPU box (with gloo)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend=os.environ.get("IDEAS_DIST_BACKEND", "nccl"), init_method="env://")
+
+    from ideas_amd import checkpoint, data as D, train_step as TS
+    from ideas_amd.ddp import GradReducer, broadcast_parameters
+    from ideas_amd.models import init_model
+    from ideas_amd.optim import fuse_optimizers
+
+    base_dir = f"experiments/{args.exp_name}"
+    ckpt_dir = f"{base_dir}/checkpoints"
+    if rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+
+    torch.manual_seed(args.seed)               # identical replicas on every rank
+    trainer = TS.build_trainer(args, "cpu", init_model)
+    if args.ckpt is not None:
+        args.start_iter = checkpoint.load(args.ckpt, trainer)          # train.py:435-442
+    for v in trainer.values():
+        if isinstance(v, torch.nn.Module):
+            v.to(device)
+    if world > 1:
+        broadcast_parameters([v for v in trainer.values() if isinstance(v, torch.nn.Module)])
+    fuse_optimizers(trainer, args)
+    reducer = GradReducer() if world > 1 else None
+    random.seed(args.seed + 1000 + rank)       # crops and draws differ per rank, replicas do not
+    torch.manual_seed(args.seed + 1000 + rank)
+
+    dataset = D.set_dataset(args.dataset_type, args.dataset_path, args.image_size)
+    sampler = D.data_sampler(dataset, shuffle=True, rank=rank, world=world, seed=args.seed)
+    loader = D.DeviceLoader(dataset, args.batch_size, sampler, device=device, num_workers=args.num_workers,
+                            seed=args.seed + rank, drop_last=True)
+    if rank == 0:
+        print(f"Data Loaded: {len(dataset)} images, {len(loader)} batches of {args.batch_size} per rank, {world} rank(s)", flush=True)
+
+    batches = D.sample_data(loader)
+    start_time = time.time()
+    epoch_len = max(len(loader), 1)
+    for idx in range(1, args.num_iters - args.start_iter + 1):
+        iter_idx = idx + args.start_iter
+        if (idx - 1) % epoch_len == 0:
+            sampler.set_epoch((idx - 1) // epoch_len)
+        X = next(batches)
+        losses = TS.train_iteration(trainer, args, X, iter_idx, reducer=reducer)
+
+        if iter_idx % args.log_every == 0 and rank == 0:               # train.py:223-247
+            v = {k: float(t) for k, t in losses.items() if t.numel() == 1}
+            used = time.time() - start_time
+            rest = used / idx * (args.num_iters - iter_idx)
+            line = (f"[{iter_idx:07d}/{args.num_iters:07}] Total: {v['Loss_total']:.4f}; "
+                    f"G,rec: {v['G_rec_loss']:.4f}; G,texture: {v['G_texture_loss']:.4f}; G,real: {v['G_real_loss']:.4f}; "
+                    f"E,dist: {v['E_dist_loss']:.4f}; E,stru: {v['E_stru_loss']:.4f}; Ex: {v['Ex_loss']:.4f} "
+                    f"used time: {time_change(used)};rest time: {time_change(rest)}")
+            print(line, flush=True)
+            with open(f"{base_dir}/training_logs.txt", "a") as fp:
+                fp.write(line + "\n")
+
+        if iter_idx % args.show_every == 0 and rank == 0:              # train.py:249-293 (test block; no image grid)
+            with torch.no_grad():
+                s = args.image_size // 16
+                M = torch.randint(low=0, high=2, dtype=torch.float, size=(X.shape[0], args.N * s * s))
+                T2 = torch.rand(X.shape[0], args.texture_channel, device=device) * 2 - 1
+                use_x3 = iter_idx > args.num_iters * 0.8
+                _, _, acc, l1 = TS.extraction_test(trainer, args, X, M, T2, use_x3)
+            line = (f"[Testing {iter_idx:07d}/{args.num_iters:07d}] sigma=1 delta=50% using synthesised image "
+                    f"\\hatX_{3 if use_x3 else 2} ACC of Msg: {float(acc):.4f}; L1 loss of tensor: {float(l1):.4f}")
+            print(line, flush=True)
+            with open(f"{base_dir}/training_logs.txt", "a") as fp:
+                fp.write(line + "\n")
+
+        if (iter_idx % args.save_every == 0 or iter_idx == args.num_iters) and rank == 0:    # train.py:308-322
+            checkpoint.save(f"{ckpt_dir}/{iter_idx:07d}.pt", trainer, args, iter_idx)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
