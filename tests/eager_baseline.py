@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stock PyTorch-ROCm eager comparator: the oracle's restatement of the reference step (composite torch ops,
 MIOpen convolutions, per-sample grouped modulated convs exactly like the reference) timed on cuda:0.
-Benchmark-side tool only (BASELINE.md §3 'GPU comparators'); the product never imports the oracle."""
+Checker-side tool (lives under tests/ because it runs the oracle; the product never imports it)."""
 import argparse
 import json
 import os
