@@ -617,3 +617,50 @@ def test_grad_sink_matches_plain_autograd(ops):
     torch.cuda.synchronize()
     for p, g in zip(params, ref):
         assert rel_err(p.grad, 2 * g) < 2e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))
+
+
+def test_b3_full_size_properties():
+    """BASELINE-size checks of the split-bf16 kernels (G.layers.7.conv2: 128->128 @256x256 and the stride-2 / transposed
+    neighbours, B=8) through size-independent properties: linearity in the input, agreement between the Winograd (4- and
+    8-wave), direct-split and f32-MFMA kernels, <gy, conv(x)> == <dgrad(gy), x> == <wgrad(gy, x), w>."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd import _lib
+    from ideas_amd.op.conv_plan import ConvGeom
+    torch.manual_seed(0)
+    B, C, R = 8, 128, 256
+    x1 = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL)
+    x2 = torch.randn(B, C, R, R, device="cuda").contiguous(memory_format=CL)
+    w = torch.randn(C, C, 3, 3, device="cuda").contiguous(memory_format=CL)
+    gain = 1 / math.sqrt(C * 9)
+    math0, wino0 = CV.MATH, CV.B3_WINO
+    try:
+        CV.MATH = _lib.F32_B3
+        for stride, pad in ((1, 1), (2, 0)):
+            g = ConvGeom(3, 3, stride, pad, False)
+            CV.B3_WINO = True
+            y1, y2 = CV.conv_fwd_raw(x1, w, g, gain), CV.conv_fwd_raw(x2, w, g, gain)
+            y12 = CV.conv_fwd_raw(x1 + 2 * x2, w, g, gain)
+            assert rel_err(y12, y1 + 2 * y2) < 5e-6, stride
+            CV.B3_WINO = False
+            yd = CV.conv_fwd_raw(x1, w, g, gain)                       # direct split kernel
+            CV.MATH = _lib.F32
+            yf = CV.conv_fwd_raw(x1, w, g, gain)                       # f32 MFMA kernels
+            CV.MATH, CV.B3_WINO = _lib.F32_B3, True
+            assert rel_err(y1, yd) < 5e-6 and rel_err(y1, yf) < 5e-6, (stride, rel_err(y1, yd), rel_err(y1, yf))
+            gy = torch.randn_like(y1)
+            gx = CV.conv_dgrad_raw(gy, w, g, (R, R), gain)
+            lhs = float((gy.double() * y1.double()).sum())
+            rhs = float((gx.double() * x1.double()).sum())
+            assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3, (stride, lhs, rhs)
+            gw = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)
+            lhs_w = float((gw.double() * w.double()).sum())
+            assert abs(lhs_w - lhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3, (stride, lhs_w, lhs)
+            del y1, y2, y12, yd, yf, gy, gx, gw
+        # the 4-wave and the 8-wave Winograd tiles are the same arithmetic in a different order
+        g = ConvGeom(3, 3, 1, 1, False)
+        y8 = CV.conv_fwd_raw(x1, w, g, gain)
+        w64 = w[:64].contiguous(memory_format=CL)                       # Cout = 64 -> the 4-wave tile
+        y4 = CV.conv_fwd_raw(x1, w64, g, gain)
+        assert rel_err(y4, y8[:, :64]) < 2e-6
+    finally:
+        CV.MATH, CV.B3_WINO = math0, wino0
