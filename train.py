@@ -29,29 +29,19 @@ def time_change(t: float) -> str:
 
 def main():
     p = argparse.ArgumentParser()
-    p.add_argument("--exp_name", type=str, required=True)
-    p.add_argument("--dataset_path", type=str, required=True)
-    p.add_argument("--dataset_type", choices=['lmdb', 'normal'], required=True)
-    p.add_argument("--num_iters", type=int, required=True)
-    p.add_argument("--N", type=int, default=1)
-    p.add_argument("--lambda_Ex", type=float, default=10)
-    p.add_argument("--ckpt", type=str, default=None)
-    p.add_argument("--lr", type=float, default=0.002)
-    p.add_argument("--batch_size", type=int, default=1)
-    p.add_argument("--image_size", type=int, default=256)
-    p.add_argument("--real_r1", type=float, default=10)
-    p.add_argument("--texture_r1", type=float, default=1)
-    p.add_argument("--dist_r1", type=float, default=1)
-    p.add_argument("--ref_crop", type=int, default=4)
-    p.add_argument("--n_crop", type=int, default=8)
-    p.add_argument("--d_reg_every", type=int, default=16)
-    p.add_argument("--channel", type=int, default=32)
-    p.add_argument("--channel_multiplier", type=int, default=1)
-    p.add_argument("--structure_channel", type=int, default=8)
-    p.add_argument("--texture_channel", type=int, default=2048)
-    p.add_argument("--log_every", type=int, default=200)
-    p.add_argument("--show_every", type=int, default=1000)
-    p.add_argument("--save_every", type=int, default=200000)
+    # the reference's flags (train.py:331-367): name, type, default (None = required)
+    for name, typ, default in (("exp_name", str, None), ("dataset_path", str, None), ("num_iters", int, None),
+                               ("N", int, 1), ("lambda_Ex", float, 10), ("ckpt", str, ""), ("lr", float, 0.002),
+                               ("batch_size", int, 1), ("image_size", int, 256), ("real_r1", float, 10),
+                               ("texture_r1", float, 1), ("dist_r1", float, 1), ("ref_crop", int, 4), ("n_crop", int, 8),
+                               ("d_reg_every", int, 16), ("channel", int, 32), ("channel_multiplier", int, 1),
+                               ("structure_channel", int, 8), ("texture_channel", int, 2048), ("log_every", int, 200),
+                               ("show_every", int, 1000), ("save_every", int, 200000)):
+        if default is None:
+            p.add_argument("--" + name, type=typ, required=True)
+        else:
+            p.add_argument("--" + name, type=typ, default=default)
+    p.add_argument("--dataset_type", choices=["lmdb", "normal"], required=True)
     # additions of this build
     p.add_argument("--no_dco", action="store_true", help="drop the co-occurrence discriminator terms (image_size < 256)")
     p.add_argument("--num_workers", type=int, default=4)
@@ -88,7 +78,7 @@ def main():
 
     torch.manual_seed(args.seed)               # identical replicas on every rank
     trainer = TS.build_trainer(args, "cpu", init_model)
-    if args.ckpt is not None:
+    if args.ckpt:
         args.start_iter = checkpoint.load(args.ckpt, trainer)          # train.py:435-442
     for v in trainer.values():
         if isinstance(v, torch.nn.Module):
