@@ -94,10 +94,13 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
+        # (x * scale) @ W^T instead of x @ (W * scale)^T (stylegan2/model.py:152-160): the same product re-associated, with
+        # the [B, in] activation scaled instead of the [out, in] weight (and no scaled-weight pass in the backward either)
+        x = input * self.scale
+        b = self.bias if (self.bias is None or self.lr_mul == 1) else self.bias * self.lr_mul
         if self.activation:
-            return fused_leaky_relu(F.linear(input, self.weight * self.scale), self.bias * self.lr_mul)
-        b = None if self.bias is None else self.bias * self.lr_mul
-        return F.linear(input, self.weight * self.scale, bias=b)
+            return fused_leaky_relu(F.linear(x, self.weight), b)
+        return F.linear(x, self.weight, bias=b)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
