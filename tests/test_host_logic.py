@@ -189,3 +189,32 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     s1, s2 = tr["d_optim"].state_dict(), tr2["d_optim"].state_dict()
     assert s1["param_groups"] == s2["param_groups"]
     assert all(torch.equal(s1["state"][i]["exp_avg_sq"], s2["state"][i]["exp_avg_sq"]) for i in s1["state"])
+
+
+def test_derived_weight_cache_scope():
+    """op/conv_plan.py cache: off by default (plain op calls never see stale derived weights), memoises only (views of)
+    Parameters while on, and is emptied by cache_clear() -- which train_step._step calls after every optimiser step."""
+    import torch
+    from ideas_amd.op import conv_plan as P
+    w = torch.nn.Parameter(torch.randn(4, 3, 3, 3))
+    calls = []
+
+    def make():
+        calls.append(1)
+        return w.detach() * 2
+    assert P._CACHE is None
+    P.cached(w, ("k",), make); P.cached(w, ("k",), make)
+    assert len(calls) == 2                                   # cache off: recomputed every time
+    P.cache_begin()
+    try:
+        a = P.cached(w, ("k",), make); b = P.cached(w, ("k",), make)
+        assert a is b and len(calls) == 3                    # memoised
+        assert P.cached(w[:2], ("k",), make) is not a        # another view: another entry
+        t = torch.randn(4, 3, 3, 3)                          # not a Parameter: never cached
+        P.cached(t, ("k",), make); P.cached(t, ("k",), make)
+        n = len(calls)
+        P.cache_clear()                                      # what an optimiser step triggers
+        assert P.cached(w, ("k",), make) is not a and len(calls) == n + 1
+    finally:
+        P.cache_end()
+    assert P._CACHE is None
