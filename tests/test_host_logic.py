@@ -218,3 +218,34 @@ def test_derived_weight_cache_scope():
     finally:
         P.cache_end()
     assert P._CACHE is None
+
+
+def test_committed_bench_line_meets_the_contract():
+    """profiles/r01_bench_default.json is a verbatim `python bench.py` line: every field of the bench contract is there."""
+    import json
+    import os
+    d = json.loads(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                     "r01_bench_default.json")).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 32 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 0.05 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
+
+
+def test_lmdb_dataset_fails_loudly_without_lmdb():
+    import importlib.util
+    import pytest
+    from ideas_amd import data as D
+    if importlib.util.find_spec("lmdb") is None:
+        with pytest.raises(ImportError):
+            D.set_dataset("lmdb", "/nonexistent", 64)
