@@ -262,8 +262,10 @@ int launch_b3_wgrad_cfg(float* gw, const void* gy, const void* x, const float* i
 extern "C" int ideas_b3_wgrad_supported(const ideas_conv_params* p) {
     if (!p) return 0;
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
-    // (Cout <= 64 and tiny reductions stay on the f32 kernels: half-empty tiles / atomics-dominated there, measured slower)
-    if (p->Cout <= 64 || (P < 16384 && (int64_t)p->TY * p->TX * p->Cin < 2048)) return 0;
+    // (Cout <= 32 and tiny reductions stay on the f32 kernels: half-empty tiles / atomics-dominated there, measured slower;
+    //  32 < Cout <= 64 runs a 64 x 192 tile -- all four waves stage, 18 MFMAs per wave and step -- which beats the f32
+    //  Winograd weight gradient by 8-20 % there; a 64 x 128 tile with an idle staging wave did not)
+    if (p->Cout <= 32 || (P < 16384 && (int64_t)p->TY * p->TX * p->Cin < 2048)) return 0;
     return p->Cin % 4 == 0 && p->Cout % 4 == 0 && p->OW % 4 == 0 && (p->OW % 16 == 0 || 16 % p->OW == 0) &&
            16 / p->OW <= p->OH && P % 16 == 0 && P < 0x7fffffffLL &&
            (int64_t)p->B * p->IH * p->IW * p->Cin * 4 < 0xffffffffLL && (int64_t)p->B * p->YH * p->YW * p->Cout * 4 < 0xffffffffLL;
@@ -272,5 +274,6 @@ extern "C" int ideas_b3_wgrad_supported(const ideas_conv_params* p) {
 // called by ideas_conv_wgrad for dtype IDEAS_F32_B3 once the arguments are validated and ideas_b3_wgrad_supported
 int ideas_b3_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                    const ideas_conv_params* p, hipStream_t stream) {
+    if (p->Cout <= 64) return launch_b3_wgrad_cfg<2, 2, 1, 3>(gw, gy, x, in_scale, out_scale, p, stream);   // 64 (o) x 192 (k)
     return launch_b3_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 128 (o) x 128 (k)
 }
