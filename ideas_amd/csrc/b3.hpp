@@ -13,12 +13,6 @@ constexpr int BK = 16;     // f32 K depth of one pipeline step = K of one bf16 M
 constexpr int ROWB = 32;   // bytes per LDS row (16 bf16)
 constexpr unsigned RSRC_FLAGS = 0x00020000u;   // raw buffer, 32-bit data format
 
-__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
-    const int q = nblk >> 3, rem = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-}
-
 // two f32 -> one dword of two RNE bf16 (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     const f32x2 v = {a, b};

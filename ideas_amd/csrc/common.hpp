@@ -21,6 +21,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Workgroup id -> tile id so that each XCD (block b runs on XCD b % 8, private 4 MiB L2) owns a contiguous band of tiles.
+// Bijective for any grid size (the q/rem form of cdna_hip_programming.md T1).
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
+    const int q = nblk >> 3, rem = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
 // mirror an out-of-range coordinate back into [0,n) (ReflectionPad2d semantics, no edge repeat)
 __device__ __forceinline__ int reflect_coord(int i, int n) {
     if (i < 0) i = -i;

@@ -351,8 +351,7 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
                       const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
     const int64_t M = (int64_t)p->B * p->IH * (p->IW / 2);
     const int64_t tm = ideas_cdiv(M, WP);
-    static const bool force4 = getenv("IDEAS_B3_WINO8") && getenv("IDEAS_B3_WINO8")[0] == '0';   // A/B measurements only
-    const bool wide = p->Cin % 32 == 0 && p->Cout > 64 && !force4;     // 8-wave 64 x 128 tile, K-step 32
+    const bool wide = p->Cin % 32 == 0 && p->Cout > 64;     // 8-wave 64 x 128 tile, K-step 32
     const int tn = (int)ideas_cdiv(p->Cout, wide ? 2 * WN : WN);
     if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);

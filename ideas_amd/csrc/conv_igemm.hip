@@ -33,12 +33,6 @@ namespace {
 constexpr int BK = 16;    // K (or pixel) depth of one pipeline step
 constexpr int LDK = 20;   // padded LDS row length (floats) of the K-contiguous tiles
 
-__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
-    const int q = nblk >> 3, rem = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-}
-
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 // component-wise select: a ternary on the float4 aggregates becomes a select between two ADDRESSES, which forces
 // the staging registers into scratch memory (seen in the ISA as scratch_store + vmcnt(0) after every load)

@@ -5,7 +5,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void reflect_fold_kernel(float4* __restrict__ gx, const float4* __restrict__ gp, int B,
+__device__ __forceinline__ void acc_add(float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+__device__ __forceinline__ void acc_add(float& a, const float& v) { a += v; }
+__device__ __forceinline__ void acc_zero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void acc_zero(float& a) { a = 0.f; }
+
+// V = float4 (C % 4 == 0, C4 = C / 4) or float (any C, C4 = C)
+template <typename V>
+__global__ __launch_bounds__(256) void reflect_fold_kernel(V* __restrict__ gx, const V* __restrict__ gp, int B,
                                                            int H, int W, int C4, int pad) {
     const int64_t total = (int64_t)B * H * W * C4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -23,12 +30,10 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(float4* __restrict__ 
         xs[nx++] = x + pad;
         if (x >= 1 && x <= pad) xs[nx++] = pad - x;
         if (x >= W - 1 - pad && x <= W - 2) xs[nx++] = 2 * (W - 1) + pad - x;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        V acc;
+        acc_zero(acc);
         for (int a = 0; a < ny; ++a)
-            for (int e = 0; e < nx; ++e) {
-                const float4 v = gp[(((int64_t)b * Hp + ys[a]) * Wp + xs[e]) * C4 + c];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
+            for (int e = 0; e < nx; ++e) acc_add(acc, gp[(((int64_t)b * Hp + ys[a]) * Wp + xs[e]) * C4 + c]);
         gx[i] = acc;
     }
 }
@@ -40,11 +45,16 @@ extern "C" int ideas_reflect_fold(void* gx, const void* gpadded, int B, int H, i
     if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
     if (!gx || !gpadded) return IDEAS_E_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad <= 0 || pad >= H || pad >= W) return IDEAS_E_SHAPE;
-    if ((C & 3) || !ideas_aligned16(gx) || !ideas_aligned16(gpadded)) return IDEAS_E_ALIGN;
-    const int64_t total = (int64_t)B * H * W * (C / 4);
+    const bool vec = !(C & 3) && ideas_aligned16(gx) && ideas_aligned16(gpadded);
+    const int C4 = vec ? C / 4 : C;
+    const int64_t total = (int64_t)B * H * W * C4;
     int64_t grid = ideas_cdiv(total, 256);
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float4*)gx,
-                       (const float4*)gpadded, B, H, W, C / 4, pad);
+    if (vec)
+        hipLaunchKernelGGL(reflect_fold_kernel<float4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float4*)gx,
+                           (const float4*)gpadded, B, H, W, C4, pad);
+    else   // channel counts that are not a multiple of 4 (the N-channel / RGB ends of Gstru, Ex, E): scalar path
+        hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float*)gx,
+                           (const float*)gpadded, B, H, W, C4, pad);
     return ideas_launch_status();
 }

@@ -170,14 +170,11 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
         ph, pw = in_hw[0] + 2 * g.pad, in_hw[1] + 2 * g.pad
         gxp = conv_dgrad_raw(gy, w, gp, (ph, pw), gain, lin, lout)
         b, c = gxp.shape[0], gxp.shape[1]
-        if c % 4 == 0:
-            gx = torch.empty((b, c, in_hw[0], in_hw[1]), device=gxp.device, dtype=gxp.dtype, memory_format=CL)
-            rc = _lib.load().ideas_reflect_fold(_lib.ptr(gx), _lib.ptr(gxp), b, in_hw[0], in_hw[1], c, g.pad, _lib.F32,
-                                                _lib.stream_ptr())
-            _lib.check(rc, "ideas_reflect_fold")
-            return gx
-        like = gxp.new_empty((b, c, in_hw[0], in_hw[1]))
-        return torch.ops.aten.reflection_pad2d_backward(gxp.contiguous(), like, [g.pad] * 4)
+        gx = torch.empty((b, c, in_hw[0], in_hw[1]), device=gxp.device, dtype=gxp.dtype, memory_format=CL)
+        rc = _lib.load().ideas_reflect_fold(_lib.ptr(gx), _lib.ptr(gxp), b, in_hw[0], in_hw[1], c, g.pad, _lib.F32,
+                                            _lib.stream_ptr())
+        _lib.check(rc, "ideas_reflect_fold")
+        return gx
     if in_hw == (gy.shape[2], gy.shape[3]) and _b3_wino_ok(g, gy.shape[1], w.shape[1], gy.shape[3]):
         b, co, h, wd = gy.shape
         ci = w.shape[1]

@@ -19,6 +19,7 @@ from typing import Optional
 
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import _lib
 from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, weight_grad, _nhwc
@@ -81,6 +82,7 @@ class _ModConv(Function):
         return y
 
     @staticmethod
+    @once_differentiable          # raw kernels below: a create_graph pass must use second_order() and raises otherwise
     def backward(ctx, gy):
         x, w, s, d, y = ctx.saved_tensors
         d = d if ctx.has_d else None
@@ -105,7 +107,9 @@ class _ModConv(Function):
                 gw = weight_grad(w, lambda out: conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out),
                                  x, gy, s, d)
         if need_s:
-            # gx = s * (dL/d(s*x)); <x, gx> / s = <x, dL/d(s*x)>
+            # gx = s * (dL/d(s*x)); <x, gx> / s = <x, dL/d(s*x)>.  Where s == 0 exactly the quotient is undefined and 0 is
+            # returned (the true value needs a second, unscaled input-gradient launch; s = affine(style) with bias 1 never
+            # hits an exact zero in training — DESIGN.md §5)
             dot = pixel_dot(x, gx)
             gs = torch.where(s != 0, dot / s, torch.zeros_like(dot))
         if need_d and d is not None:
@@ -144,6 +148,7 @@ class _ModConvAct(Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x, w, s, d, b, y = ctx.saved_tensors
         g, gain = ctx.g, ctx.gain

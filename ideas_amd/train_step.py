@@ -120,10 +120,18 @@ def _params_of(trainer, names) -> List[torch.Tensor]:
     return [p for n in names for p in trainer[n].parameters()]
 
 
-def _step(opt) -> None:
+def _step(opt, ema: bool = True) -> None:
     """Optimiser step + invalidation of the derived-weight cache (op/conv_plan.py): the fused Adam kernel writes the
-    parameters behind autograd's back, so nothing derived from them may outlive it."""
-    opt.step()
+    parameters behind autograd's back, so nothing derived from them may outlive it.  ``ema=False``: a FusedAdamEMA step
+    that leaves the EMA copies alone (decay 1: ema = 1 * ema + 0 * p) — for iterations that step a group twice."""
+    decay = getattr(opt, "ema_decay", None)
+    if not ema and decay is not None:
+        opt.ema_decay = 1.0
+    try:
+        opt.step()
+    finally:
+        if not ema and decay is not None:
+            opt.ema_decay = decay
     conv_plan.cache_clear()
 
 
@@ -264,6 +272,7 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     losses["Loss_total"] = loss_total.detach()
     losses["hat_Z"] = hat_Z.detach()
 
+    path_step = bool(args.path_regularize) and iter_idx % args.g_reg_every == 0
     if args.elide_second_backward:
         # Ex's gradient over the Ex sub-graph only, everything else from Loss_total; both accumulate IN PLACE into the
         # optimisers' gradient buffers (flat buckets when the fused optimiser / DDP reducer own them)
@@ -274,7 +283,7 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         with grad_sink(g_params):
             torch.autograd.backward(loss_total, inputs=g_params)
         _sync("g", g_params)
-        _step(T["g_optim"])
+        _step(T["g_optim"], ema=not path_step)     # one EMA accumulate per iteration
         _sync("ex", ex_params)
         _step(T["ex_optim"])
     else:
@@ -291,13 +300,13 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         T["ex_optim"].zero_grad(set_to_none=True)
         loss_total.backward()
         _sync("g", g_params)
-        _step(T["g_optim"])
+        _step(T["g_optim"], ema=not path_step)     # one EMA accumulate per iteration
         _set_grads(ex_params, ex_grads)
         _sync("ex", ex_params)
         _step(T["ex_optim"])
 
     # ------------------------------------------------------------------ optional lazy path-length reg (not in IDEAS)
-    if args.path_regularize and iter_idx % args.g_reg_every == 0:
+    if path_step:
         losses.update(path_length_step(T, args, X.shape[0], X.shape[-1], X.device, reducer=reducer))
 
     # ------------------------------------------------------------------ EMA (train.py:218-221)
@@ -350,15 +359,23 @@ def path_length_step(trainer, args, batch: int, image_size: int, device, Z: Opti
         grads = torch.autograd.grad(weighted, g_params, allow_unused=True)
     trainer["mean_path_length"] = mean_new
     all_g = _params_of(T_, G_SIDE)
-    for p in all_g:
-        p.grad = None
-    _set_grads(g_params, grads)
+    opt = T_["g_optim"]
+    # Start from clean gradients: the fused optimiser / DDP bucket keep the main G-phase gradients in their flat buffer (one
+    # memset clears it and re-binds the views); torch's Adam drops them (set_to_none) and then skips parameters without one.
+    opt.zero_grad()
+    for p, g in zip(g_params, grads):
+        if g is None:
+            continue
+        if p.grad is None:
+            p.grad = g
+        else:
+            p.grad.add_(g)
     if reducer is not None:
         for p in all_g:                      # the flat bucket expects every parameter of the group
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         reducer("g", all_g)
-    _step(T_["g_optim"])
+    _step(opt)        # carries the iteration's single EMA accumulate (stylegan2/train.py:272 runs it after the regulariser)
     return {"path_loss": penalty.detach(), "path_length": lengths.mean().detach()}
 
 

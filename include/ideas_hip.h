@@ -191,7 +191,7 @@ int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, 
                       int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
 
 /* Adjoint of ReflectionPad2d(pad) in NHWC: gx [B,H,W,C] = fold of gpadded [B,H+2pad,W+2pad,C] (mirrored border rows /
- * columns added back onto their sources).  C % 4 == 0.  Used by the input gradient of the reflect-padded 3x3 convs of
+ * columns added back onto their sources).  Any C (16-byte vectors when C % 4 == 0).  Used by the input gradient of the reflect-padded 3x3 convs of
  * E / Gstru / Ex (models.py:102-106). */
 int ideas_reflect_fold(void* gx, const void* gpadded, int B, int H, int W, int C, int pad, int dtype, void* stream);
 

@@ -69,3 +69,17 @@ def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     denom = float(b.abs().max())
     return float((a - b).abs().max()) / (denom if denom > 0 else 1.0)
+
+
+SKETCH_K = 8
+
+
+def sketch(grad, index):
+    """Same K seeded +-1 projections tests/golden/make_golden.py::sketch stored for every parameter gradient of the
+    reference's train(): |sketch(g) - sketch(g_ref)| / (sqrt(K) |g_ref|) estimates the relative error of the whole tensor,
+    direction included, from 8 numbers."""
+    if grad is None:
+        return [0.0] * SKETCH_K
+    gen = torch.Generator().manual_seed(900000 + index)
+    signs = torch.randint(0, 2, (SKETCH_K, grad.numel()), generator=gen, dtype=torch.int8).to(torch.float64) * 2 - 1
+    return (signs @ grad.detach().double().cpu().contiguous().view(-1)).tolist()

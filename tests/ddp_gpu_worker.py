@@ -1,0 +1,112 @@
+"""Worker of tests/test_ddp_gpu.py: one rank of a 2-rank data-parallel run of the PRODUCT path on ONE GPU (gloo backend).
+
+Launched by ``python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 ... tests/ddp_gpu_worker.py``.
+Exactly the branch the 8-GPU bench takes (bench.py with world > 1): HIP networks -> ``fuse_optimizers`` (flat parameter /
+gradient / moment buffers) -> ``GradReducer`` adopting the optimiser's flat gradient buffer as the all-reduce bucket ->
+``grad_sink`` (weight gradients accumulated on the side stream straight into that bucket) — only the transport differs
+(gloo instead of RCCL, because both ranks share GPU 0).  Stands for stylegan2/train.py:426-438.
+
+Checks, per rank:
+  1. every parameter's .grad is a view of its group's flat bucket, and the side stream of the sink was used;
+  2. after each of two iterations (the second one takes the R1 branch) the replicas are BIT-identical;
+  3. the rank-mean D-phase gradient of iteration 1 equals the full-batch gradient a single process computes.
+"""
+import os
+import random
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", init_method="env://")
+    from ideas_amd import train_step as TS
+    from ideas_amd.ddp import GradReducer
+    from ideas_amd.models import init_model
+    from ideas_amd.op import conv as CV
+    from ideas_amd.optim import fuse_optimizers
+    from test_nets_gpu import ZeroDco
+
+    args = TS.default_args(channel=8, texture_channel=128, channel_multiplier=0.25, image_size=64, batch_size=2,
+                           d_reg_every=2, num_iters=10)
+
+    def fresh():
+        torch.manual_seed(3)                    # identical replicas by seeding, as bench.py does
+        tr = TS.build_trainer(args, "cpu", init_model, dco_factory=ZeroDco)
+        for v in tr.values():
+            if isinstance(v, torch.nn.Module):
+                v.cuda()
+        fuse_optimizers(tr, args)
+        return tr
+
+    B = 2                                        # per rank
+    gen = torch.Generator().manual_seed(100)
+    Xall = (torch.rand(world * B, 3, 64, 64, generator=gen) * 2 - 1).cuda().contiguous(memory_format=torch.channels_last)
+    Zall = (torch.rand(4, world * B, 1, 4, 4, generator=gen) * 2 - 1).cuda()
+    Tall = (torch.rand(4, world * B, 128, generator=gen) * 2 - 1).cuda()
+    random.seed(9)
+    torch.manual_seed(9)
+    boxes = [[TS.draw_boxes(64, 64, n) for n in (8, 8, 32, 8, 32)] for _ in range(2)]
+
+    def draws(it, sl):
+        b = boxes[it]
+        return TS.StepDraws(Z_d=Zall[2 * it, sl], T2_d=Tall[2 * it, sl], boxes_d_fake=b[0], boxes_d_real=b[1], boxes_d_ref=b[2],
+                            Z_g=Zall[2 * it + 1, sl], T2_g=Tall[2 * it + 1, sl], boxes_g_fake=b[3], boxes_g_ref=b[4])
+
+    tr = fresh()
+    reducer = GradReducer()
+    grads = {}
+
+    def hook(tag, ps):
+        if tag not in grads:
+            grads[tag] = torch.cat([p.grad.detach().flatten().clone() for p in ps])
+
+    sl = slice(rank * B, (rank + 1) * B)
+    for it in range(2):
+        TS.train_iteration(tr, args, Xall[sl], it + 1, draws=draws(it, sl), reducer=reducer, hook=hook)
+        torch.cuda.synchronize()
+        # (1) the plumbing under test really ran
+        for key in ("d_optim", "g_optim", "ex_optim"):
+            opt = tr[key]
+            lo, hi = opt.flat_g.data_ptr(), opt.flat_g.data_ptr() + 4 * opt.flat_g.numel()
+            assert all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in opt._params), key
+        assert CV._SINK["stream"] is not None, "grad_sink side stream never used"
+        assert not reducer.buckets, "GradReducer built its own bucket instead of adopting the fused optimiser's"
+        # (2) replicas stay bit-identical (parameters, second moments, EMA copies)
+        for key in ("d_optim", "g_optim", "ex_optim"):
+            for buf in ("flat_p", "flat_v", "flat_ema"):
+                t = getattr(tr[key], buf)
+                if t is None:
+                    continue
+                got = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(got, t)
+                assert all(torch.equal(got[0], g) for g in got[1:]), f"replicas diverged after iteration {it + 1}: {key}.{buf}"
+    # (3) rank-mean of shard gradients == gradient of the global batch mean
+    if rank == 0:
+        ref = fresh()
+        g1 = {}
+
+        def hook1(tag, ps):
+            if tag not in g1:
+                g1[tag] = torch.cat([p.grad.detach().flatten().clone() for p in ps])
+        TS.train_iteration(ref, args, Xall, 1, draws=draws(0, slice(0, world * B)), hook=hook1)
+        # 'd' precedes every optimiser step: f32 noise only.  'g' / 'ex' follow the D step, whose first Adam update is
+        # lr * sign(g): noise-floor parameters may move the other way (tests/test_nets_gpu.py::check_replay), so looser.
+        for tag, tol in (("d", 1e-4), ("g", 3e-2), ("ex", 3e-2)):
+            err = float((grads[tag] - g1[tag]).abs().max() / g1[tag].abs().max())
+            assert err < tol, (tag, err)
+            print(f"rank-mean vs full-batch gradient [{tag}]: rel err {err:.2e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -361,6 +361,59 @@ def gen_init(RM, RU, RL, RO):
         json.dump(res, f)
 
 
+def load_reference_function(rel_path, name):
+    """Compile ONE function out of a reference file that cannot be imported as a module (stylegan2/train.py does
+    `from model import ...`, torchvision, lmdb at import time): parse the file, keep only that FunctionDef, exec it with
+    torch/math in scope.  Nothing of the text is stored — only the tensors it computes."""
+    import ast
+    import math
+    src = open(os.path.join(REF, rel_path)).read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(fns) == 1, (rel_path, name)
+    mod = ast.Module(body=fns, type_ignores=[])
+    scope = {"torch": torch, "math": math, "autograd": torch.autograd}
+    exec(compile(mod, os.path.join(REF, rel_path), "exec"), scope)
+    return scope[name]
+
+
+def gen_pathlen(RM, RU, RL, RO):
+    """Path-length regulariser (stylegan2/train.py:85-98, g_path_regularize) applied to the IDEAS generator with
+    latents := the texture code viewed [B, 1, C].  Weights = the tiny G of nets_tiny.npz."""
+    fn = load_reference_function("stylegan2/train.py", "g_path_regularize")
+    z = np.load(os.path.join(HERE, "nets_tiny.npz"))
+    G = RM.init_model("Generator", tiny_args(64))
+    G.load_state_dict({k[len("G/sd/"):]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("G/sd/")}, strict=True)
+    g = torch.Generator().manual_seed(31)
+    B = 3
+    S = torch.randn(B, 8, 4, 4, generator=g)
+    T = torch.rand(B, 64, generator=g) * 2 - 1
+    noise = torch.randn(B, 3, 64, 64, generator=g)
+    out = {"S": npy(S), "T": npy(T), "noise": npy(noise)}
+    o_randn_like = torch.randn_like
+    for tag, mean0 in (("a", 0.0), ("b", 0.37)):
+        latents = T.clone().view(B, 1, 64).requires_grad_(True)
+        img = G(S, latents[:, 0])
+        torch.randn_like = lambda t, **k: noise.clone()        # the function draws its noise itself (train.py:86)
+        try:
+            pen, mean, lengths = fn(img, latents, torch.tensor(mean0))
+        finally:
+            torch.randn_like = o_randn_like
+        params = [p for p in G.parameters()]
+        grads = torch.autograd.grad(pen, params, allow_unused=True)
+        out[f"{tag}.mean0"] = np.array(mean0, np.float32)
+        out[f"{tag}.penalty"], out[f"{tag}.mean"], out[f"{tag}.lengths"] = npy(pen), npy(mean), npy(lengths)
+        out[f"{tag}.gparam_norms"] = np.array([0.0 if q is None else float(q.double().norm()) for q in grads], np.float64)
+        names = [n_ for n_, _ in G.named_parameters()]
+        for n_ in ("layers.0.conv1.conv.weight", "layers.4.conv1.conv.modulation.weight", "layers.7.conv2.conv.weight",
+                   "layers.7.conv2.activate.bias"):
+            q = grads[names.index(n_)]
+            out[f"{tag}.g/{n_}"] = npy(q if q is not None else torch.zeros(1))
+    out["img"] = npy(img)
+    np.savez_compressed(os.path.join(HERE, "pathlen.npz"), **out)
+    print("pathlen.npz", len(out), "arrays; penalty", float(pen), "lengths", lengths.tolist())
+
+
 # --------------------------------------------------------------------------------------------
 class ZeroDco(torch.nn.Module):
     """Stand-in for Dco below R=256, where the reference's own Dco cannot run on 16x16 / 32x32 patches
@@ -375,6 +428,20 @@ class ZeroDco(torch.nn.Module):
         return o, o
 
 
+SKETCH_K = 8
+_RANDINT = torch.randint      # the unpatched function: run_reference_train() records every torch.randint call as a message draw
+
+
+def sketch(grad, index):
+    """K seeded +-1 projections of one gradient tensor (f64): a direction fingerprint that costs 8 numbers per parameter.
+    |sketch(g) - sketch(g_ref)| / (sqrt(K) |g_ref|) estimates |g - g_ref| / |g_ref| (tests/test_nets_gpu.py::check_replay)."""
+    if grad is None:
+        return [0.0] * SKETCH_K
+    gen = torch.Generator().manual_seed(900000 + index)
+    signs = _RANDINT(0, 2, (SKETCH_K, grad.numel()), generator=gen, dtype=torch.int8).to(torch.float64) * 2 - 1
+    return (signs @ grad.detach().double().cpu().contiguous().view(-1)).tolist()
+
+
 class SpyOptim:
     def __init__(self, opt, name, log):
         self.opt, self.name, self.log = opt, name, log
@@ -383,11 +450,14 @@ class SpyOptim:
         self.opt.zero_grad()
 
     def step(self):
-        norms = []
+        norms, sk = [], []
+        i = 0
         for grp in self.opt.param_groups:
             for p in grp["params"]:
                 norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
-        self.log.append((self.name, norms))
+                sk.append(sketch(p.grad, i))
+                i += 1
+        self.log.append((self.name, norms, sk))
         self.opt.step()
 
     def state_dict(self):
@@ -509,20 +579,29 @@ def gen_step(RM, RU, RL, RO, which):
         R, B, n_iters, zero_dco = 64, 2, 2, True
     elif which == "r64_N2":                      # BASELINE.json configs[3]/[4]: N = 2 (two secret channels)
         R, B, n_iters, zero_dco, N = 64, 2, 1, True, 2
+    elif which == "r128":                        # BASELINE.json configs[1]: 128x128, batch 16 (Dco cannot run below 256)
+        R, B, n_iters, zero_dco = 128, 16, 2, True
+    elif which == "r256_N2":                     # configs[3]'s per-GPU shape: N = 2 at 256x256, real Dco
+        R, B, n_iters, zero_dco, N = 256, 1, 2, False, 2
     else:
         R, B, n_iters, zero_dco = 256, 1, 2, False
     args = tiny_args(R, N=N)
     args.__dict__.update(num_iters=n_iters, start_iter=0, lambda_Ex=10.0, lr=0.002, batch_size=B, real_r1=10.0,
                          texture_r1=1.0, dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=2,
                          log_every=1, show_every=n_iters, save_every=10 ** 9)
-    seed = {"r64": 77, "r64_N2": 79}.get(which, 78)
+    seed = {"r64": 77, "r64_N2": 79, "r128": 80, "r256_N2": 81}.get(which, 78)
     gx = torch.Generator().manual_seed(seed + 100)
     X = torch.rand(B, 3, R, R, generator=gx) * 2 - 1
     trainer, draws, log, losses, test_lines = run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco)
-    out = {"X": npy(X), "seed": np.array(seed)}
+    out = {"seed": np.array(seed)}
+    if X.numel() <= 3 * 256 * 256:
+        out["X"] = npy(X)
+    else:   # large batches: the replay regenerates X from the seeded generator above and checks these two numbers
+        out["X_seed"] = np.array(seed + 100)
+        out["X_check"] = np.array([float(X.double().sum()), float(X.double().abs().sum())])
     out["meta"] = np.array(json.dumps(dict(R=R, B=B, N=N, n_iters=n_iters, zero_dco=zero_dco, d_reg_every=2, channel=4,
                                            texture_channel=64, cm_den=8, test_lines=test_lines,
-                                           opt_log=[[n_, len(v)] for n_, v in log])))
+                                           opt_log=[[n_, len(v)] for n_, v, _ in log])))
     for i, z in enumerate(draws["Z"]):
         out[f"Z{i}"] = npy(z)          # raw U[0,1) draws; the step uses z*2-1
     for i, t in enumerate(draws["T2"]):
@@ -533,8 +612,9 @@ def gen_step(RM, RU, RL, RO, which):
         out[f"M{i}"] = npy(m)
     for i, j in enumerate(draws["jitter"]):
         out[f"jitter{i}"] = npy(j)
-    for i, (n_, norms) in enumerate(log):
+    for i, (n_, norms, sk) in enumerate(log):
         out[f"opt{i}.{n_}.gradnorms"] = np.array(norms, np.float64)
+        out[f"sketch{i}"] = np.array(sk, np.float64)          # [n_params, SKETCH_K]
     for i, ld in enumerate(losses):
         hz = ld.pop("hat_Z")
         out[f"hatZ{i}"] = npy(hz)
@@ -552,7 +632,7 @@ def gen_step(RM, RU, RL, RO, which):
 
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["ops", "nets", "init", "step_r64", "step_r256", "step_r64_N2"]
+    todo = sys.argv[1:] or ["ops", "nets", "init", "step_r64", "step_r256", "step_r64_N2", "step_r128", "step_r256_N2", "pathlen"]
     mods = import_reference()
     torch.set_num_threads(8)
     if "ops" in todo:
@@ -567,3 +647,9 @@ if __name__ == "__main__":
         gen_step(*mods, "r256")
     if "step_r64_N2" in todo:
         gen_step(*mods, "r64_N2")
+    if "step_r128" in todo:
+        gen_step(*mods, "r128")
+    if "step_r256_N2" in todo:
+        gen_step(*mods, "r256_N2")
+    if "pathlen" in todo:
+        gen_pathlen(*mods)

@@ -458,7 +458,7 @@ def test_full_size_blur_and_bias_act_properties():
     assert torch.allclose(gxa[pos], torch.full_like(gxa[pos], 2 ** 0.5)) and torch.allclose(gxa[~pos], torch.full_like(gxa[~pos], 0.2 * 2 ** 0.5))
 
 
-@pytest.mark.parametrize("shape,pad", [((2, 8, 6, 9), 1), ((1, 32, 34, 34), 1), ((2, 4, 5, 4), 2)])
+@pytest.mark.parametrize("shape,pad", [((2, 8, 6, 9), 1), ((1, 32, 34, 34), 1), ((2, 4, 5, 4), 2), ((2, 3, 7, 6), 1), ((1, 2, 5, 5), 2)])
 def test_reflect_fold_is_the_adjoint_of_reflection_pad(shape, pad):
     """ideas_reflect_fold (input-gradient fold of the reflect-padded convs) == autograd of F.pad(mode='reflect')."""
     from ideas_amd import _lib

@@ -222,3 +222,31 @@ def test_c_oracle_against_golden(ops_golden):
         if m["up"]:
             y = OC.upfirdn2d(y, k1 * 4, pad=(1, 1))
         assert rel_err(torch.from_numpy(y), g.t(f"mod{i}.y")) < 5e-6, m
+
+
+def test_path_length_regulariser_matches_reference_function():
+    """oracle.g_path_regularize + oracle.generator vs the vectors the reference's own g_path_regularize
+    (stylegan2/train.py:85-98, compiled out of the file by tests/golden/make_golden.py::gen_pathlen) produced on the tiny
+    generator of nets_tiny.npz: penalty, running mean, per-sample lengths and parameter gradients of the penalty."""
+    from conftest import Golden
+    g, nets = Golden("pathlen.npz"), Golden("nets_tiny.npz")
+    cfg = O.Cfg(channel=4, structure_channel=8, texture_channel=64, N=1, image_size=64, channel_multiplier=0.125)
+    P = {k[len("G/sd/"):]: nets.t(k) for k in nets.keys() if k.startswith("G/sd/")}
+    names = [k for k in P if not k.endswith("kernel")]
+    for k in names:
+        P[k] = P[k].clone().requires_grad_(True)
+    S, T, noise = g.t("S"), g.t("T"), g.t("noise")
+    for tag in ("a", "b"):
+        Tr = T.clone().requires_grad_(True)
+        img = O.generator(P, cfg, S, Tr)
+        pen, mean, lengths = O.g_path_regularize(img, Tr, g.t(f"{tag}.mean0"), noise=noise)
+        assert rel_err(lengths, g.t(f"{tag}.lengths")) < 1e-5
+        assert abs(float(pen) - float(g.t(f"{tag}.penalty"))) <= 1e-5 * abs(float(g.t(f"{tag}.penalty")))
+        assert abs(float(mean) - float(g.t(f"{tag}.mean"))) <= 1e-6 * abs(float(g.t(f"{tag}.mean")))
+        grads = torch.autograd.grad(pen, [P[k] for k in names], allow_unused=True)
+        norms = torch.tensor([0.0 if q is None else float(q.double().norm()) for q in grads], dtype=torch.float64)
+        assert torch.allclose(norms, g.t(f"{tag}.gparam_norms"), rtol=1e-3, atol=1e-8)
+        for k in g.keys():
+            if k.startswith(f"{tag}.g/"):
+                assert rel_err(grads[names.index(k[len(tag) + 3:])], g.t(k)) < 1e-4, k
+    assert rel_err(img, g.t("img")) < 1e-5

@@ -27,11 +27,81 @@ def test_train_cli_runs_logs_saves_and_resumes(tmp_path):
     log = (tmp_path / "experiments/t0/training_logs.txt").read_text()
     assert "[0000002/0000004] Total:" in log and "[0000004/0000004] Total:" in log
     assert "[Testing 0000003/0000004] sigma=1 delta=50%" in log and "ACC of Msg:" in log
-    ckpt = tmp_path / "experiments/t0/checkpoints/0000004.pt"
+    ckpt = tmp_path / "experiments/t0/checkpoints/4.pt"            # the reference's file name (train.py:320)
     assert ckpt.exists()
+    # resume by path into a new experiment ...
     r = subprocess.run(base + ["--exp_name", "t1", "--num_iters", "6", "--save_every", "100", "--ckpt", str(ckpt)],
                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     log = (tmp_path / "experiments/t1/training_logs.txt").read_text()
     assert "[0000006/0000006] Total:" in log and "[0000002/" not in log      # resumed at iteration 5
-    assert (tmp_path / "experiments/t1/checkpoints/0000006.pt").exists()
+    assert (tmp_path / "experiments/t1/checkpoints/6.pt").exists()
+    # ... and by bare name inside the same experiment, as the reference does (train.py:436-438: --ckpt 4)
+    r = subprocess.run(base + ["--exp_name", "t0", "--num_iters", "6", "--save_every", "100", "--ckpt", "4"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "experiments/t0/checkpoints/6.pt").exists()
+
+
+@pytest.mark.gpu
+def test_small_shard_fails_loudly_instead_of_spinning(tmp_path):
+    from PIL import Image
+    data_dir = tmp_path / "imgs"
+    data_dir.mkdir()
+    for i in range(2):
+        Image.fromarray(np.zeros((64, 64, 3), np.uint8)).save(data_dir / f"{i}.png")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--dataset_path", str(data_dir), "--dataset_type",
+                        "normal", "--image_size", "64", "--batch_size", "4", "--no_dco", "--num_workers", "0",
+                        "--exp_name", "t", "--num_iters", "1"], cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "fewer than --batch_size" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_resume_keeps_adam_state_of_the_fused_optimizers(tmp_path):
+    """Save after two iterations, resume into freshly fused optimisers: second moments, step counts, parameters and EMA
+    copies survive, and the next iteration is bit-identical to the one the uninterrupted trainer takes."""
+    import torch
+    from ideas_amd import checkpoint, train_step as TS
+    from ideas_amd.models import init_model
+    from ideas_amd.optim import fuse_optimizers
+
+    def fresh():
+        args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=64, batch_size=2,
+                               d_reg_every=2, num_iters=10, use_dco=False)
+        torch.manual_seed(5)
+        tr = TS.build_trainer(args, "cpu", init_model)
+        for v in tr.values():
+            if isinstance(v, torch.nn.Module):
+                v.cuda()
+        fuse_optimizers(tr, args)
+        return tr, args
+
+    tr, args = fresh()
+    g = torch.Generator().manual_seed(6)
+    X = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).cuda()
+    draws = []
+    for it in (1, 2, 3):
+        torch.manual_seed(100 + it)
+        draws.append(TS.draw_step(args, 2, 64, X.device))
+    for it in (1, 2):
+        TS.train_iteration(tr, args, X, it, draws=draws[it - 1])
+    path = str(tmp_path / "2.pt")
+    checkpoint.save(path, tr, args, 2)
+    tr2, _ = fresh()
+    assert checkpoint.load(path, tr2, map_location="cuda") == 2
+    for k in ("g_optim", "ex_optim", "d_optim"):
+        assert tr2[k]._steps == tr[k]._steps > 0, k
+        assert torch.equal(tr2[k].flat_v, tr[k].flat_v) and float(tr[k].flat_v.abs().sum()) > 0, k
+        assert torch.equal(tr2[k].flat_p, tr[k].flat_p), k
+    assert torch.equal(tr2["g_optim"].flat_ema, tr["g_optim"].flat_ema)
+    for p in tr2["G"].parameters():      # still views of the flat buffer the fused kernel updates
+        lo, hi = tr2["g_optim"].flat_p.data_ptr(), tr2["g_optim"].flat_p.data_ptr() + 4 * tr2["g_optim"].flat_p.numel()
+        assert lo <= p.data_ptr() < hi
+    la = TS.train_iteration(tr, args, X, 3, draws=draws[2])
+    lb = TS.train_iteration(tr2, args, X, 3, draws=draws[2])
+    assert abs(float(la["Loss_total"]) - float(lb["Loss_total"])) <= 1e-5 * abs(float(la["Loss_total"]))
+    for k in ("g_optim", "d_optim"):
+        d = (tr[k].flat_p - tr2[k].flat_p).abs()
+        # atomics order perturbs noise-floor gradients; an Adam update is bounded by lr / sqrt(1 - beta2)
+        assert float(d.max()) <= 12 * args.lr and float(d.mean()) <= 1e-2 * args.lr, (k, float(d.max()), float(d.mean()))

@@ -22,9 +22,15 @@ import torch.distributed as dist
 
 
 def time_change(t: float) -> str:
-    """utils.py: h/m/s formatting of the log line."""
-    t = int(t)
-    return f"{t // 3600:d}h{(t % 3600) // 60:02d}m{t % 60:02d}s"
+    """utils.py:12-34: '1h 2m 3s' / '2m 3s' / '3s' (thresholds strictly greater than one hour / one minute)."""
+    if t / 3600 > 1:
+        h = int(t / 3600)
+        m = int((t - h * 3600) / 60)
+        return f"{h}h {m}m {int(t - h * 3600 - m * 60)}s"
+    if t / 60 > 1:
+        m = int(t / 60)
+        return f"{m}m {int(t - m * 60)}s"
+    return f"{int(t)}s"
 
 
 def main():
@@ -78,14 +84,19 @@ def main():
 
     torch.manual_seed(args.seed)               # identical replicas on every rank
     trainer = TS.build_trainer(args, "cpu", init_model)
-    if args.ckpt:
-        args.start_iter = checkpoint.load(args.ckpt, trainer)          # train.py:435-442
     for v in trainer.values():
         if isinstance(v, torch.nn.Module):
             v.to(device)
+    # Fuse FIRST, then resume: FusedAdamEMA.load_state_dict copies exp_avg_sq / step into its flat buffers and the module
+    # load_state_dict copies into the flat parameter views, so the Adam state of the checkpoint survives (train.py:435-442).
+    fuse_optimizers(trainer, args)
+    if args.ckpt:
+        # the reference resolves a bare name as experiments/<exp>/checkpoints/<ckpt>.pt (train.py:436-438); a path works too
+        path = args.ckpt if os.path.isfile(args.ckpt) else f"{ckpt_dir}/{args.ckpt}.pt"
+        print("load model:", path, flush=True)
+        args.start_iter = checkpoint.load(path, trainer, map_location=device)
     if world > 1:
         broadcast_parameters([v for v in trainer.values() if isinstance(v, torch.nn.Module)])
-    fuse_optimizers(trainer, args)
     reducer = GradReducer() if world > 1 else None
     random.seed(args.seed + 1000 + rank)       # crops and draws differ per rank, replicas do not
     torch.manual_seed(args.seed + 1000 + rank)
@@ -94,6 +105,9 @@ def main():
     sampler = D.data_sampler(dataset, shuffle=True, rank=rank, world=world, seed=args.seed)
     loader = D.DeviceLoader(dataset, args.batch_size, sampler, device=device, num_workers=args.num_workers,
                             seed=args.seed + rank, drop_last=True)
+    if len(loader) == 0:
+        raise SystemExit(f"dataset shard of rank {rank} has {len(sampler)} images, fewer than --batch_size {args.batch_size}: "
+                         "no full batch can be formed (lower --batch_size or add images)")
     if rank == 0:
         print(f"Data Loaded: {len(dataset)} images, {len(loader)} batches of {args.batch_size} per rank, {world} rank(s)", flush=True)
 
@@ -133,7 +147,7 @@ def main():
                 fp.write(line + "\n")
 
         if (iter_idx % args.save_every == 0 or iter_idx == args.num_iters) and rank == 0:    # train.py:308-322
-            checkpoint.save(f"{ckpt_dir}/{iter_idx:07d}.pt", trainer, args, iter_idx)
+            checkpoint.save(f"{ckpt_dir}/{iter_idx}.pt", trainer, args, iter_idx)   # the reference's file name
 
     if world > 1:
         dist.barrier()
