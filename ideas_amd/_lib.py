@@ -17,6 +17,16 @@ LIB_PATH = os.environ.get("IDEAS_HIP_LIB", os.path.join(_HERE, "libideas_hip.so"
 NCHW, NHWC = 0, 1
 F32 = 0
 F32_B3 = 1   # f32 tensors, split-bf16 contraction (IDEAS_F32_B3)
+BF16 = 2     # bf16 activations, bf16 MFMA with f32 accumulation, f32 master weights (IDEAS_BF16)
+
+
+def act_dtype(t: torch.Tensor) -> int:
+    """dtype enum of the elementwise / reduction entry points for an activation tensor."""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"ideas_amd: only float32 and bfloat16 activations are implemented, got {t.dtype}")
 
 
 class ConvParams(C.Structure):
@@ -48,6 +58,10 @@ _PROTOS = {
     "ideas_b3_wino_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wino_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P]),
     "ideas_b3_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_bf16_conv_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int]),
+    "ideas_bf16_wgrad_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int]),
+    "ideas_bf16_direct_supported": (C.c_int, [C.POINTER(ConvParams)]),
+    "ideas_bf16_pack_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_conv3x3_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv3x3_wino_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv_direct": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
@@ -58,7 +72,7 @@ _PROTOS = {
     "ideas_reflect_fold": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_adam_ema": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "ideas_image_u8_to_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
-    "ideas_act_bwd_dot": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
+    "ideas_act_bwd_dot": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
 }
 EXPORTS = tuple(_PROTOS)
 

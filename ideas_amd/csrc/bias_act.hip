@@ -29,9 +29,9 @@ __device__ __forceinline__ float act_one(float v, float r, const ActArgs& a) {
 }
 
 // ---- NHWC / [B,C]: channel = i % C, vectorised by 4 along C ------------------------------------
-template <bool HAS_B, bool HAS_REF, bool BGRAD, bool TILED>
-__global__ __launch_bounds__(256) void bias_act_nhwc_v4(float4* __restrict__ y, const float4* __restrict__ x,
-                                                        const float* __restrict__ b, const float4* __restrict__ ref,
+template <typename V, bool HAS_B, bool HAS_REF, bool BGRAD, bool TILED>
+__global__ __launch_bounds__(256) void bias_act_nhwc_v4(V* __restrict__ y, const V* __restrict__ x,
+                                                        const float* __restrict__ b, const V* __restrict__ ref,
                                                         float* __restrict__ bgrad, int64_t n4, int C, ActArgs a) {
     extern __shared__ float s_bg[];
     constexpr int U = 4;
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_v4(float4* __restrict__ y, 
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i < n4) {
-                v[u] = x[i];
-                if (HAS_REF) r[u] = ref[i];
+                v[u] = to_f4(x[i]);
+                if (HAS_REF) r[u] = to_f4(ref[i]);
             }
         }
 #pragma unroll
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_v4(float4* __restrict__ y, 
             float4 o;
             o.x = act_one(vv.x, rr.x, a); o.y = act_one(vv.y, rr.y, a);
             o.z = act_one(vv.z, rr.z, a); o.w = act_one(vv.w, rr.w, a);
-            y[i] = o;
+            y[i] = from_f4<V>(o);
             if (BGRAD) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
         }
     }
@@ -90,17 +90,17 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_v4(float4* __restrict__ y, 
 }
 
 // scalar NHWC fallback (C % 4 != 0 or unaligned): one element per thread-iteration
-template <bool BGRAD>
-__global__ __launch_bounds__(256) void bias_act_nhwc_s(float* __restrict__ y, const float* __restrict__ x,
-                                                       const float* __restrict__ b, const float* __restrict__ ref,
+template <typename T, bool BGRAD>
+__global__ __launch_bounds__(256) void bias_act_nhwc_s(T* __restrict__ y, const T* __restrict__ x,
+                                                       const float* __restrict__ b, const T* __restrict__ ref,
                                                        float* __restrict__ bgrad, int64_t n, int C, ActArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int c = (int)(i % C);
-        float v = x[i];
+        float v = ld1(x + i);
         if (b) v += b[c];
-        float o = act_one(v, ref ? ref[i] : 0.f, a);
-        y[i] = o;
+        float o = act_one(v, ref ? ld1(ref + i) : 0.f, a);
+        st1(y + i, o);
         if (BGRAD) atomicAdd(&bgrad[c], o);
     }
 }
@@ -161,7 +161,8 @@ int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 extern "C" int ideas_fused_bias_act(void* y, const void* x, const void* b, const void* ref, float* bias_grad,
                                     int64_t n, int C, int64_t inner, int layout, int act, int grad, float alpha,
                                     float scale, int dtype, void* stream_) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
+    if (dtype == IDEAS_BF16 && layout != IDEAS_NHWC && inner != 1) return IDEAS_E_UNSUPPORTED;   // bf16: NHWC / [B,C] only
     if (n == 0) return IDEAS_OK;
     if (!y || !x) return IDEAS_E_NULL;
     if (n < 0 || C <= 0 || inner <= 0) return IDEAS_E_SHAPE;
@@ -178,7 +179,7 @@ extern "C" int ideas_fused_bias_act(void* y, const void* x, const void* b, const
 
     if (layout == IDEAS_NHWC || inner == 1) {
         if (n % C != 0) return IDEAS_E_SHAPE;
-        const bool vec = (C % 4 == 0) && ideas_aligned16(x) && ideas_aligned16(y) && (!rf || ideas_aligned16(rf)) &&
+        const bool vec = (C % 4 == 0) && ideas_aligned16(x) && ideas_aligned16(y) && (!rf || ideas_aligned16(ref)) &&
                          (!bf || ideas_aligned16(bf)) && C <= 8192;
         if (vec) {
             const int64_t n4 = n / 4;
@@ -194,14 +195,13 @@ extern "C" int ideas_fused_bias_act(void* y, const void* x, const void* b, const
                 grid = ideas_cdiv(n4, 1024);
                 if (grid > 4096) grid = 4096;
             }
+#define LAUNCH_V4T(V, HB, HR, BG, TL)                                                                                    \
+    hipLaunchKernelGGL((bias_act_nhwc_v4<V, HB, HR, BG, TL>), dim3((unsigned)grid), dim3(256), lds, stream, (V*)y,      \
+                       (const V*)x, bf, (const V*)((grad == 1) ? ref : nullptr), bias_grad, n4, C, a)
 #define LAUNCH_V4(HB, HR, BG)                                                                                            \
     do {                                                                                                                 \
-        if (tiled)                                                                                                       \
-            hipLaunchKernelGGL((bias_act_nhwc_v4<HB, HR, BG, true>), dim3((unsigned)grid), dim3(256), lds, stream,      \
-                               (float4*)yf, (const float4*)xf, bf, (const float4*)rf, bias_grad, n4, C, a);              \
-        else                                                                                                             \
-            hipLaunchKernelGGL((bias_act_nhwc_v4<HB, HR, BG, false>), dim3((unsigned)grid), dim3(256), lds, stream,     \
-                               (float4*)yf, (const float4*)xf, bf, (const float4*)rf, bias_grad, n4, C, a);              \
+        if (dtype == IDEAS_BF16) { if (tiled) LAUNCH_V4T(ideas_bf16x4, HB, HR, BG, true); else LAUNCH_V4T(ideas_bf16x4, HB, HR, BG, false); } \
+        else { if (tiled) LAUNCH_V4T(float4, HB, HR, BG, true); else LAUNCH_V4T(float4, HB, HR, BG, false); }           \
     } while (0)
             if (bias_grad) {
                 if (bf && rf) LAUNCH_V4(true, true, true);
@@ -214,15 +214,16 @@ extern "C" int ideas_fused_bias_act(void* y, const void* x, const void* b, const
             else if (rf) LAUNCH_V4(false, true, false);
             else LAUNCH_V4(false, false, false);
 #undef LAUNCH_V4
+#undef LAUNCH_V4T
         } else {
             int64_t grid = ideas_cdiv(n, 256);
             if (grid > 8192) grid = 8192;
-            if (bias_grad)
-                hipLaunchKernelGGL((bias_act_nhwc_s<true>), dim3((unsigned)grid), dim3(256), 0, stream, yf, xf, bf, rf,
-                                   bias_grad, n, C, a);
-            else
-                hipLaunchKernelGGL((bias_act_nhwc_s<false>), dim3((unsigned)grid), dim3(256), 0, stream, yf, xf, bf, rf,
-                                   bias_grad, n, C, a);
+#define LAUNCH_S(T, BG)                                                                                                  \
+    hipLaunchKernelGGL((bias_act_nhwc_s<T, BG>), dim3((unsigned)grid), dim3(256), 0, stream, (T*)y, (const T*)x, bf,    \
+                       (const T*)((grad == 1) ? ref : nullptr), bias_grad, n, C, a)
+            if (dtype == IDEAS_BF16) { if (bias_grad) LAUNCH_S(ideas_bf16, true); else LAUNCH_S(ideas_bf16, false); }
+            else { if (bias_grad) LAUNCH_S(float, true); else LAUNCH_S(float, false); }
+#undef LAUNCH_S
         }
         return ideas_launch_status();
     }

@@ -29,6 +29,32 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
 }
 
+// ---- activation element access for the two storage dtypes: f32 arithmetic either way --------------------------------
+typedef unsigned short ideas_bf16;                 // one bf16 element in HBM
+struct ideas_bf16x4 { uint2 v; };                  // four consecutive bf16 (8 bytes)
+__device__ __forceinline__ unsigned ideas_pk_bf16(float a, float b) {          // two f32 -> two RNE bf16 (v_cvt_pk_bf16_f32)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ t = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2_));
+}
+__device__ __forceinline__ float4 to_f4(float4 v) { return v; }
+__device__ __forceinline__ float4 to_f4(ideas_bf16x4 p) {
+    return make_float4(__builtin_bit_cast(float, p.v.x << 16), __builtin_bit_cast(float, p.v.x & 0xffff0000u),
+                       __builtin_bit_cast(float, p.v.y << 16), __builtin_bit_cast(float, p.v.y & 0xffff0000u));
+}
+template <typename V> __device__ __forceinline__ V from_f4(float4 v);
+template <> __device__ __forceinline__ float4 from_f4<float4>(float4 v) { return v; }
+template <> __device__ __forceinline__ ideas_bf16x4 from_f4<ideas_bf16x4>(float4 v) {
+    ideas_bf16x4 r;
+    r.v = make_uint2(ideas_pk_bf16(v.x, v.y), ideas_pk_bf16(v.z, v.w));
+    return r;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const ideas_bf16* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(ideas_bf16* p, float v) { *p = (ideas_bf16)(ideas_pk_bf16(v, 0.f) & 0xffffu); }
+
 // mirror an out-of-range coordinate back into [0,n) (ReflectionPad2d semantics, no edge repeat)
 __device__ __forceinline__ int reflect_coord(int i, int n) {
     if (i < 0) i = -i;
@@ -58,3 +84,8 @@ int ideas_b3_wgrad(float* gw, const void* gy, const void* x, const float* in_sca
 // conv_b3_wino.hip: 3x3/s1/p1 Winograd F(2,3) with the split contraction (uplanes from ideas_b3_wino_split_weights)
 int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* in_scale, const float* out_scale,
                       const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);
+// conv_bf16.hip: bf16 mixed-precision family (dtype IDEAS_BF16): bf16 activations, packed bf16 weights (ideas_bf16_pack_weights)
+int ideas_bf16_fwd(void* y, const void* x, const void* wpack, const float* in_scale, const float* out_scale, const float* bias,
+                   const void* resid, const ideas_conv_params* p, hipStream_t stream);
+int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                     const ideas_conv_params* p, hipStream_t stream);

@@ -1,0 +1,638 @@
+// bf16 mixed-precision convolution family for gfx950 (BASELINE.json configs[4]): bf16 activations in HBM (NHWC), bf16
+// operands on v_mfma_f32_32x32x16_bf16 (ONE product per MFMA — no split), f32 accumulation, f32 epilogue, f32 master
+// weights and f32 weight gradients.  Same GEMM view, parameterisation (ideas_conv_params) and epilogue as
+// conv_igemm.hip / conv_b3.hip; what changes is how the operands travel:
+//
+//   forward family (forward convs, input gradients, the parity phases of transposed convs)
+//     * K-step = 32 channels of one tap (two MFMA K-slices); LDS rows are 64 bytes, 16-byte chunk c of row r lives at
+//       position c ^ ((r >> 2) & 3): the ds_read_b128 operand fetches (four 16-lane groups) are conflict-free;
+//     * activations go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.  The DMA
+//       writes lane l's 16 bytes at base + 16 l, so the swizzle and the im2col gather both live in the per-lane SOURCE
+//       offset; a padding tap gets offset 0xffffffff, for which the DMA writes zeros (probed: tools/probes/dma.hip);
+//     * weights are packed once per optimiser step (ideas_bf16_pack_weights) into [K/32][Cout][32] bf16 with that swizzle
+//       already applied, so a B tile is one contiguous block that the DMA copies linearly;
+//     * modulated convs (per-sample input scale s[b, ci]): M tiles are cut per image (a tile never straddles two samples; the
+//       last tile of an image is partial), so the block scales its WEIGHT tile by s[b, :] on the way into LDS — the reference's per-sample weights (stylegan2/model.py:240-248)
+//       materialised per block in LDS instead of per sample in HBM; the activation path stays pure DMA;
+//     * the MFMA runs with the weights as its A operand: a lane then owns ONE pixel and four consecutive output channels per
+//       accumulator quad, i.e. the epilogue packs 4 bf16 and issues 8-byte stores (4x fewer store instructions than a
+//       channel-per-lane layout with 2-byte stores).
+//
+//   weight gradient  gw[o][k] += gain * sum_p G(p, o) X(p, k)
+//     * both operands are pixel-major in HBM; the MFMA wants 8 consecutive PIXELS of one channel per lane.  The tiles are
+//       DMA'd as they lie ([32 pixels][channels]) and transposed by the LDS itself: ds_read_b64_tr_b16 hands lane l the four
+//       rows of column l & 15 of a 4 x 16 block whose 8-byte pieces the 16 lanes of its group point at (probed:
+//       tools/probes/tr.hip).  16-byte chunks are XOR-swizzled across the four pixel rows of a block so that the 32 lanes of a
+//       half-wave hit 32 different bank pairs;
+//     * split-K over blockIdx.y with f32 atomics into the (flat-bucket) f32 gradient; for modulated convs every split lies
+//       inside one image and the per-sample scales d[b,o] * s[b,ci] are applied to the accumulator in the epilogue.
+#include "common.hpp"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;      // storage type of a bf16 element in HBM
+
+namespace {
+
+constexpr int KB = 32;          // bf16 K depth of one pipeline step (two MFMA K-slices)
+constexpr int ROW = 64;         // bytes per LDS row of the forward kernel
+constexpr unsigned RSRC = 0x00020000u;
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+__device__ __forceinline__ float bf_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+__device__ __forceinline__ uint4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights: f32 [Cout][K] (K = (ty, tx, ci) contiguous) -> bf16 [K/32][Cout][32], K-step = (ci/32, ty, tx), 16-byte chunk c of
+// row n stored at position c ^ ((n >> 2) & 3)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(uint4* __restrict__ dst, const float4* __restrict__ w, int Cout, int K,
+                                                           int Cin) {
+    const int64_t n8 = (int64_t)Cout * (K / 8);
+    const int ntaps = K / Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % (K / 8)) * 8;
+        const int n = (int)(i / (K / 8));
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int step = (ci >> 5) * ntaps + tap;
+        const int c = (ci & 31) >> 3;
+        const float4 a = w[2 * i], b = w[2 * i + 1];
+        const uint4 v = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
+        dst[((int64_t)step * Cout + n) * 4 + (c ^ ((n >> 2) & 3))] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward family
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+                                                           const void* __restrict__ wpack, const float* __restrict__ in_scale,
+                                                           const float* __restrict__ out_scale, const float* __restrict__ bias,
+                                                           const bf16_t* __restrict__ resid, ideas_conv_params p, int tiles_n,
+                                                           int tiles_per_img, unsigned x_bytes, unsigned w_bytes) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = WM * MT * 32;      // pixels of the tile
+    constexpr int BN = WN * NT * 32;      // output channels of the tile
+    static_assert(BM % 64 == 0, "each wave issues whole 16-row DMA pieces");
+    constexpr int A_PER = BM / 64;        // 16-row DMA pieces of the A tile per wave
+    constexpr int B_PIECES = BN / 16;     // 16-row pieces of the B tile (spread over the waves)
+    constexpr int B_PER = (B_PIECES + 3) / 4;
+    constexpr int BUF = (BM + BN) * ROW;
+    constexpr int SMEM = 2 * BUF > BM * 12 ? 2 * BUF : BM * 12;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t M = (int64_t)p.B * p.OH * p.OW;
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int n0 = tile_n * BN;
+    // row r of the tile -> output point.  Plain: consecutive points of the flattened (b, oy, ox) grid.  SCALE: tiles are cut
+    // per image (tile_m = img * tiles_per_img + j), rows past the image's last point are clamped and not stored.
+    const int OHW = p.OH * p.OW;
+    const int img = SCALE ? tile_m / tiles_per_img : 0;
+    const int64_t m0 = SCALE ? (int64_t)img * OHW + (int64_t)(tile_m - img * tiles_per_img) * BM : (int64_t)tile_m * BM;
+    const int64_t mend = SCALE ? (int64_t)(img + 1) * OHW : M;     // first point this tile must not touch
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (int)w_bytes, (int)RSRC);
+
+    // ---- A: this lane's DMA slots.  Piece q (16 rows) is issued by wave q & 3; lane l fills LDS slot l of the piece:
+    // row = 16 q + (l >> 2), position l & 3, which must hold chunk c = (l & 3) ^ ((row >> 2) & 3) of that row.
+    unsigned a_base[A_PER], a_inv[A_PER];
+    int a_iyb[A_PER], a_ixb[A_PER], a_img[A_PER], a_c8[A_PER];
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+        const int r = (wave + 4 * j) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        int64_t m = m0 + r;
+        m = m < mend ? m : mend - 1;               // rows past the end repeat the last row; their results are not stored
+        const int ox = (int)(m % p.OW);
+        const int64_t q = m / p.OW;
+        const int oy = (int)(q % p.OH);
+        const int b = (int)(q / p.OH);
+        const int iyb = oy * p.sy + p.offy, ixb = ox * p.sx + p.offx;
+        a_base[j] = (unsigned)(((b * p.IH + iyb) * p.IW + ixb) * p.Cin + c * 8) * 2u;   // mod 2^32; valid taps land < x_bytes
+        a_iyb[j] = iyb; a_ixb[j] = ixb; a_img[j] = b * p.IH; a_c8[j] = c * 8;
+        unsigned inv = 0;
+        if (!REFLECT) {
+            for (int ty = 0; ty < p.TY; ++ty)
+                for (int tx = 0; tx < p.TX; ++tx) {
+                    const int iy = iyb + ty * p.dy, ix = ixb + tx * p.dx;
+                    const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+                    inv |= (ok ? 0u : 1u) << (ty * p.TX + tx);
+                }
+        }
+        a_inv[j] = inv;
+    }
+    // ---- B
+    // plain: linear DMA of 16-row pieces (the pack is pre-swizzled); SCALE: thread t owns (row t >> 2 [+ 64 j], position t & 3)
+    constexpr int BS_PER = (BN * 4 + 255) / 256;
+    const float* srow = SCALE ? in_scale + (int64_t)img * p.Cin : nullptr;
+
+    int k_ci = 0, k_tx = 0, k_ty = 0, k_tap = 0;   // block-uniform walk over K = (ci/32, ty, tx)
+    auto advance = [&]() {
+        const int nx = k_tx + 1, gx = 1 - (int)((unsigned)(nx - p.TX) >> 31);
+        k_tx = nx - gx * p.TX;
+        const int ny = k_ty + gx, gy = 1 - (int)((unsigned)(ny - p.TY) >> 31);
+        k_ty = ny - gy * p.TY;
+        k_tap = (k_tap + 1) * (1 - gy);
+        k_ci += gy * KB;
+    };
+    auto dmaA = [&](int buf) {                      // uses (k_ty, k_tx, k_ci, k_tap) of the tile being fetched
+        unsigned char* base = smem + buf * BUF;
+        const unsigned tapoff = (unsigned)(((k_ty * p.dy) * p.IW + k_tx * p.dx) * p.Cin + k_ci) * 2u;
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) {
+            unsigned off;
+            if (REFLECT) {
+                const int iy = reflect_coord(a_iyb[j] + k_ty * p.dy, p.IH), ix = reflect_coord(a_ixb[j] + k_tx * p.dx, p.IW);
+                off = (unsigned)(((a_img[j] + iy) * p.IW + ix) * p.Cin + k_ci + a_c8[j]) * 2u;
+            } else {
+                off = (a_base[j] + tapoff) | (unsigned)__builtin_amdgcn_sbfe(a_inv[j], k_tap, 1);
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + (wave + 4 * j) * 1024), 16, (int)off, 0, 0, 0);
+        }
+    };
+    auto dmaB = [&](int buf, int kt) {
+        unsigned char* base = smem + buf * BUF + BM * ROW;
+        // (the K-step offset is folded into the per-lane offset: only that one is range-checked by a raw buffer)
+        const unsigned soff = (unsigned)kt * (unsigned)p.Cout * 64u;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+            const int q = wave + 4 * j;
+            if (q < B_PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(base + q * 1024), 16,
+                                                         (int)((unsigned)((n0 + q * 16) * 64 + lane * 16) + soff), 0, 0, 0);
+        }
+    };
+    // SCALE: register path for B (one stage): load at the top of a step, scale + store after the MFMAs
+    uint4 rb[BS_PER];
+    float4 rs0[BS_PER], rs1[BS_PER];
+    auto gloadBS = [&](int kt, int ci0) {
+        const unsigned soff = (unsigned)kt * (unsigned)p.Cout * 64u;
+#pragma unroll
+        for (int j = 0; j < BS_PER; ++j) {
+            const int r = ((t >> 2) + 64 * j) % BN;
+            const int c = (t & 3) ^ ((r >> 2) & 3);
+            rb[j] = bload4(rw, (unsigned)((n0 + r) * 64 + (t & 3) * 16) + soff, 0);
+            const int ci = ci0 + c * 8;
+            const bool ok = ci < p.Cin;             // tiles past K: any finite scale will do
+            rs0[j] = ok ? *reinterpret_cast<const float4*>(srow + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rs1[j] = ok ? *reinterpret_cast<const float4*>(srow + ci + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstoreBS = [&](int buf) {
+        unsigned char* base = smem + buf * BUF + BM * ROW;
+#pragma unroll
+        for (int j = 0; j < BS_PER; ++j) {
+            const int r = ((t >> 2) + 64 * j) % BN;
+            uint4 v = rb[j];
+            v.x = pk_bf16(bf_lo(v.x) * rs0[j].x, bf_hi(v.x) * rs0[j].y);
+            v.y = pk_bf16(bf_lo(v.y) * rs0[j].z, bf_hi(v.y) * rs0[j].w);
+            v.z = pk_bf16(bf_lo(v.z) * rs1[j].x, bf_hi(v.z) * rs1[j].y);
+            v.w = pk_bf16(bf_lo(v.w) * rs1[j].z, bf_hi(v.w) * rs1[j].w);
+            *reinterpret_cast<uint4*>(base + r * ROW + (t & 3) * 16) = v;
+        }
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment addresses: row (..)*32 + li, K-slice s, half lh -> chunk 2 s + lh at position chunk ^ ((row >> 2) & 3)
+    const int rsw = (li >> 2) & 3;
+    const int a_off = ((wm * MT) * 32 + li) * ROW;
+    const int b_off = BM * ROW + ((wn * NT) * 32 + li) * ROW;
+    const int pos0 = ((0 + lh) ^ rsw) * 16, pos1 = ((2 + lh) ^ rsw) * 16;
+
+    const int K = p.TY * p.TX * p.Cin;
+    const int nk = K / KB;
+    // prologue: tile 0 -> buffer 0
+    if (SCALE) { gloadBS(0, 0); } else dmaB(0, 0);
+    dmaA(0);
+    advance();
+    if (SCALE) lstoreBS(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        // fetch tile kt+1 (past K: padding-mask / out-of-range zeros or finite garbage that is never multiplied)
+        if (SCALE) gloadBS(kt + 1, k_ci); else dmaB(buf ^ 1, kt + 1);
+        dmaA(buf ^ 1);
+        advance();
+        const unsigned char* base = smem + buf * BUF;
+        bf16x8 fx[MT][2], fw[NT][2];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            fx[a][0] = *reinterpret_cast<const bf16x8*>(base + a_off + a * 32 * ROW + pos0);
+            fx[a][1] = *reinterpret_cast<const bf16x8*>(base + a_off + a * 32 * ROW + pos1);
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            fw[b][0] = *reinterpret_cast<const bf16x8*>(base + b_off + b * 32 * ROW + pos0);
+            fw[b][1] = *reinterpret_cast<const bf16x8*>(base + b_off + b * 32 * ROW + pos1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)   // weights as the A operand: rows of D = output channels, columns = pixels
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][s], fx[a][s], acc[a][b], 0, 0, 0);
+        if (SCALE) lstoreBS(buf ^ 1);
+        __syncthreads();                            // DMA of tile kt+1 landed (vmcnt(0) rides on the barrier); buffer `buf` is free
+    }
+
+    // ---- epilogue: lane = pixel li of block a; registers 4g..4g+3 = channels 8g + 4lh .. +3 of block b --------------------
+    int64_t* row_off = reinterpret_cast<int64_t*>(smem);
+    int* row_b = reinterpret_cast<int*>(smem + 8 * BM);
+    if (t < BM) {
+        const int64_t m = m0 + t;
+        int64_t off = -1;
+        int b = 0;
+        if (m < mend) {
+            const int ox = (int)(m % p.OW);
+            const int64_t q = m / p.OW;
+            const int oy = (int)(q % p.OH);
+            b = (int)(q / p.OH);
+            off = (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout;
+        }
+        row_off[t] = off;
+        row_b[t] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        const int row = (wm * MT + a) * 32 + li;
+        const int64_t off = row_off[row];
+        if (off < 0) continue;
+        const int bimg = row_b[row];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * NT + b) * 32 + 8 * g + 4 * lh;
+                if (n >= p.Cout) continue;           // Cout % 4 == 0
+                float v[4];
+                const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 os = out_scale ? *reinterpret_cast<const float4*>(out_scale + (int64_t)bimg * p.Cout + n)
+                                            : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, osv[4] = {os.x, os.y, os.z, os.w};
+                uint2 rr = make_uint2(0u, 0u);
+                if (resid) rr = *reinterpret_cast<const uint2*>(resid + off + n);
+                const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                uint2 prev = make_uint2(0u, 0u);
+                if (p.accumulate) prev = *reinterpret_cast<const uint2*>(y + off + n);
+                const float pv[4] = {bf_lo(prev.x), bf_hi(prev.x), bf_lo(prev.y), bf_hi(prev.y)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float u = acc[a][b][4 * g + j] * p.gain * osv[j] + bvv[j];
+                    if (p.act) u = (u > 0.f ? u : u * p.alpha) * p.act_gain;
+                    if (resid) u = (u + rv[j]) * p.resid_gain;
+                    if (p.accumulate) u += pv[j];
+                    v[j] = u;
+                }
+                *reinterpret_cast<uint2*>(y + off + n) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_bf16_cfg(void* y, const void* x, const void* wpack, const float* in_scale, const float* out_scale, const float* bias,
+                    const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    const int tpi = (int)ideas_cdiv((int64_t)p->OH * p->OW, BM_);
+    const int64_t tm = in_scale ? (int64_t)p->B * tpi : ideas_cdiv(M, BM_);
+    const int tn = (int)ideas_cdiv(p->Cout, BN_);
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
+    const unsigned w_bytes = (unsigned)((int64_t)p->TY * p->TX * p->Cin * p->Cout * 2);
+    auto go = [&](auto sc, auto rf) {
+        hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
+                           dim3(256), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack, in_scale, out_scale, bias,
+                           (const bf16_t*)resid, *p, tn, tpi, x_bytes, w_bytes);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------------------------
+// LDS image of an operand tile: [32 pixels][R channels] bf16, 16-byte chunk (8 channels) c of pixel row r at chunk slot
+// r * (R/8) + (c ^ sw(r)), where sw spreads the four rows of a transpose block over different bank groups.
+template <int R>
+__device__ __forceinline__ int chunk_slot(int r, int c) {
+    constexpr int CPR = R / 8;
+    if (CPR >= 16) return r * CPR + (c ^ ((r & 3) << 2));
+    if (CPR == 8) return r * CPR + (c ^ (((r >> 1) & 1) << 2));
+    return r * CPR + c;
+}
+
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restrict__ gw, const bf16_t* __restrict__ gy,
+                                                                 const bf16_t* __restrict__ x, const float* __restrict__ in_scale,
+                                                                 const float* __restrict__ out_scale, ideas_conv_params p,
+                                                                 int tiles_n, int pix_per_split, int splits_per_img,
+                                                                 unsigned gy_bytes, unsigned x_bytes) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int BM = WM * MT * 32;   // output channels of the tile
+    constexpr int BN = WN * NT * 32;   // k columns of the tile
+    constexpr int PIECES_G = 32 * BM * 2 / 1024, PIECES_X = 32 * BN * 2 / 1024;    // 1 KiB DMA pieces per K-step
+    constexpr int PIECES = PIECES_G + PIECES_X;
+    constexpr int PER = (PIECES + 3) / 4;
+    constexpr int BUF = 32 * (BM + BN) * 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int Ktot = p.TY * p.TX * p.Cin;
+    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    const int o0 = tile_m * BM, n0 = tile_n * BN;
+    const int P = p.B * p.OH * p.OW;
+    // plain: splits cut the flattened pixel axis; SCALE: `splits_per_img` splits per image, none straddles two samples
+    const int OHW = p.OH * p.OW;
+    const int bimg = SCALE ? blockIdx.y / splits_per_img : 0;
+    const int pbeg = SCALE ? bimg * OHW + (blockIdx.y - bimg * splits_per_img) * pix_per_split : blockIdx.y * pix_per_split;
+    const int plim = SCALE ? (bimg + 1) * OHW : P;
+    const int pend = pbeg + pix_per_split < plim ? pbeg + pix_per_split : plim;
+    if (pbeg >= pend) return;
+
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, (int)gy_bytes, (int)RSRC);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC);
+
+    // ---- this lane's DMA slots: piece q = wave + 4 j; LDS slot = 64 (q - first piece of its operand) + lane --------------
+    int s_pix[PER];                    // pixel row (0..31) within the step
+    unsigned s_cb[PER];                // byte offset of the channel chunk inside a source pixel (G: o0 + 8c; X: ci of column n0 + 8c)
+    int s_yoff[PER], s_xoff[PER];      // tap shift (X) / output placement (G)
+    bool s_valid[PER];
+    int w_b[PER], w_oy[PER], w_ox[PER], w_p[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int q = wave + 4 * j;
+        const bool is_g = q < PIECES_G;
+        const int slot = (is_g ? q : q - PIECES_G) * 64 + lane;
+        s_valid[j] = q < PIECES;
+        int r, c;
+        if (is_g) {
+            constexpr int CPR = BM / 8;
+            r = slot / CPR;
+            const int cs = slot % CPR;
+            c = CPR >= 16 ? cs ^ ((r & 3) << 2) : (CPR == 8 ? cs ^ (((r >> 1) & 1) << 2) : cs);
+            const int o = o0 + 8 * c;
+            s_cb[j] = (unsigned)o * 2u;
+            s_yoff[j] = p.ooy; s_xoff[j] = p.oox;
+            if (o >= p.Cout) s_valid[j] = false;
+        } else {
+            constexpr int CPR = BN / 8;
+            r = slot / CPR;
+            const int cs = slot % CPR;
+            c = CPR >= 16 ? cs ^ ((r & 3) << 2) : (CPR == 8 ? cs ^ (((r >> 1) & 1) << 2) : cs);
+            const int k = n0 + 8 * c;
+            const int tap = k / p.Cin, ci = k - tap * p.Cin;
+            const int ty = tap / p.TX, tx = tap - ty * p.TX;
+            s_cb[j] = (unsigned)ci * 2u;
+            s_yoff[j] = ty * p.dy + p.offy; s_xoff[j] = tx * p.dx + p.offx;
+            if (k >= Ktot) s_valid[j] = false;
+        }
+        s_pix[j] = r;
+        const int pp = pbeg + r;
+        const int qq = pp / p.OW;
+        w_ox[j] = pp - qq * p.OW;
+        w_b[j] = qq / p.OH;
+        w_oy[j] = qq - w_b[j] * p.OH;
+        w_p[j] = pp;
+    }
+    const int d_ox = 32 % p.OW, d_oy = 32 / p.OW;   // (32 | OW: d_oy = 0;  OW | 32: d_ox = 0)
+
+    auto dma = [&](int buf) {
+        unsigned char* base = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int q = wave + 4 * j;
+            if (q >= PIECES) continue;               // wave-uniform
+            const bool is_g = q < PIECES_G;
+            const int sH = is_g ? p.YH : p.IH, sW = is_g ? p.YW : p.IW, sC = is_g ? p.Cout : p.Cin;
+            int iy = w_oy[j] * (is_g ? p.osy : p.sy) + s_yoff[j];
+            int ix = w_ox[j] * (is_g ? p.osx : p.sx) + s_xoff[j];
+            bool ok = s_valid[j] && w_p[j] < pend;
+            if (REFLECT && !is_g) { iy = reflect_coord(iy, sH); ix = reflect_coord(ix, sW); }
+            else ok = ok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
+            const unsigned off = (unsigned)(((w_b[j] * sH + iy) * sW + ix) * sC) * 2u + s_cb[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(is_g ? rg : rx, LDS_PTR(base + q * 1024), 16, (int)(ok ? off : 0xffffffffu), 0, 0, 0);
+            // advance 32 pixels
+            w_p[j] += 32;
+            w_ox[j] += d_ox;
+            const bool cx = w_ox[j] >= p.OW;
+            w_ox[j] -= cx ? p.OW : 0;
+            w_oy[j] += d_oy + (cx ? 1 : 0);
+            const bool cy = w_oy[j] >= p.OH;
+            w_oy[j] -= cy ? p.OH : 0;
+            w_b[j] += cy ? 1 : 0;
+        }
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // Transpose-read addresses.  MFMA K-slice s covers pixel rows 16 s .. 16 s + 15; lane (li, lh) needs rows 16 s + 8 lh + 0..7 of
+    // channel (block) * 32 + li: two ds_read_b64_tr_b16, each over a [4 rows][16 channels] block.  Within its 16-lane group a
+    // lane POINTS at row (lane & 15) >> 2, 8-byte piece lane & 3 of the block; it RECEIVES column lane & 15.
+    const int g_q = lane & 15;
+    const int g_row = g_q >> 2, g_piece = g_q & 3;           // which row / 8-byte piece this lane points at
+    const int g_cblk = (lane >> 4) & 1;                      // 16-channel half of the 32-channel MFMA block
+    auto tr_addr = [&](int tileR_is_M, int blk, int s, int half) -> int {   // byte offset inside the operand's image
+        const int r = 16 * s + 8 * lh + 4 * half + g_row;
+        const int c = blk * 4 + g_cblk * 2 + (g_piece >> 1);                // 16-byte chunk (8 channels) index in the row
+        const int slot = tileR_is_M ? chunk_slot<BM>(r, c) : chunk_slot<BN>(r, c);
+        return slot * 16 + (g_piece & 1) * 8;
+    };
+    int a_addr[MT][2][2], b_addr[NT][2][2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) a_addr[a][s][h] = tr_addr(1, wm * MT + a, s, h);
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) b_addr[b][s][h] = 32 * BM * 2 + tr_addr(0, wn * NT + b, s, h);
+
+    auto tr_read = [&](const unsigned char* base, int off0, int off1) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + off0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + off1));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    const int nsteps = (pend - pbeg + 31) / 32;
+    dma(0);
+    __syncthreads();
+    for (int s_ = 0; s_ < nsteps; ++s_) {
+        const int buf = s_ & 1;
+        dma(buf ^ 1);                                // past pend: zero fill (never multiplied into anything that matters)
+        const unsigned char* base = smem + buf * BUF;
+        bf16x8 fa[MT][2], fb[NT][2];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fa[a][s] = tr_read(base, a_addr[a][s][0], a_addr[a][s][1]);
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fb[b][s] = tr_read(base, b_addr[b][s][0], b_addr[b][s][1]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D rows = output channels (r&3) + 8 (r>>2) + 4 lh of block a, column = k column li of block b ------------
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int k = n0 + (wn * NT + b) * 32 + li;
+        if (k >= Ktot) continue;
+        const float sk = SCALE ? in_scale[(int64_t)bimg * p.Cin + (k % p.Cin)] * p.gain : p.gain;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + (wm * MT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o >= p.Cout) continue;
+                float v = acc[a][b][r] * sk;
+                if (SCALE) v *= out_scale[(int64_t)bimg * p.Cout + o];
+                atomicAdd(&gw[(int64_t)o * Ktot + k], v);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_bf16_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                          const ideas_conv_params* p, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    const int64_t P = (int64_t)p->B * p->OH * p->OW;
+    const int Ktot = p->TY * p->TX * p->Cin;
+    const int tm = (int)ideas_cdiv(p->Cout, BM_);
+    const int tn = (int)ideas_cdiv(Ktot, BN_);
+    const int64_t tiles = (int64_t)tm * tn;
+    const bool sc = in_scale && out_scale;
+    const int64_t img = (int64_t)p->OH * p->OW;
+    // split-K: about two waves of resident blocks (2 per CU), >= 8 steps each; modulated convs: whole splits inside one image
+    const int64_t slots = 2 * 256;
+    int64_t splits = (2 * slots) / tiles;
+    if (splits < 1) splits = 1;
+    int64_t per, spi = 1;
+    if (sc) {
+        spi = splits / p->B;                         // splits per image
+        const int64_t max_spi = ideas_cdiv(img, 32 * 4);
+        if (spi > max_spi) spi = max_spi;
+        if (spi < 1) spi = 1;
+        per = ideas_cdiv(ideas_cdiv(img, spi), 32) * 32;
+        spi = ideas_cdiv(img, per);
+        splits = spi * p->B;
+    } else {
+        const int64_t max_splits = ideas_cdiv(P, 32 * 8);
+        if (splits > max_splits) splits = max_splits;
+        per = ideas_cdiv(ideas_cdiv(P, splits), 32) * 32;
+        splits = ideas_cdiv(P, per);
+    }
+    if (splits > 65535) return IDEAS_E_SHAPE;
+    const unsigned gy_bytes = (unsigned)((int64_t)p->B * p->YH * p->YW * p->Cout * 2);
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
+    auto go = [&](auto s_, auto rf) {
+        hipLaunchKernelGGL((conv_bf16_wgrad_kernel<WM, WN, MT, NT, decltype(s_)::value, decltype(rf)::value>),
+                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const bf16_t*)gy, (const bf16_t*)x,
+                           in_scale, out_scale, *p, tn, (int)per, (int)spi, gy_bytes, x_bytes);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (sc) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ideas_bf16_conv_supported(const ideas_conv_params* p, int scaled) {
+    if (!p) return 0;
+    if (p->Cin % 32 || p->Cout % 4 || p->TY * p->TX > 32) return 0;
+    if ((int64_t)p->B * p->IH * p->IW * p->Cin * 2 >= 0xffffffffLL || (int64_t)p->TY * p->TX * p->Cin * p->Cout * 2 >= 0x7fffffffLL) return 0;
+    (void)scaled;
+    return 1;
+}
+
+extern "C" int ideas_bf16_wgrad_supported(const ideas_conv_params* p, int scaled) {
+    if (!p) return 0;
+    const int64_t P = (int64_t)p->B * p->OH * p->OW;
+    if (p->Cin % 8 || p->Cout % 8) return 0;
+    if (!(p->OW % 32 == 0 || 32 % p->OW == 0) || 32 / p->OW > p->OH) return 0;
+    if (P >= 0x7fffffffLL || (int64_t)p->B * p->IH * p->IW * p->Cin * 2 >= 0xffffffffLL ||
+        (int64_t)p->B * p->YH * p->YW * p->Cout * 2 >= 0xffffffffLL)
+        return 0;
+    (void)scaled;
+    return 1;
+}
+
+extern "C" int ideas_bf16_pack_weights(void* pack, const void* wmat, int Cout, int K, int Cin, void* stream_) {
+    if (!pack || !wmat) return IDEAS_E_NULL;
+    if (Cout <= 0 || K <= 0 || Cin <= 0 || K % Cin) return IDEAS_E_SHAPE;
+    if (Cin % 32 || !ideas_aligned16(pack) || !ideas_aligned16(wmat)) return IDEAS_E_ALIGN;
+    const int64_t n8 = (int64_t)Cout * (K / 8);
+    const int blocks = (int)(n8 / 256 + 1 < 2048 ? n8 / 256 + 1 : 2048);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint4*)pack, (const float4*)wmat,
+                       Cout, K, Cin);
+    return ideas_launch_status();
+}
+
+// called by ideas_conv_igemm / ideas_conv_wgrad for dtype IDEAS_BF16 once the arguments are validated
+int ideas_bf16_fwd(void* y, const void* x, const void* wpack, const float* in_scale, const float* out_scale, const float* bias,
+                   const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, in_scale, out_scale, bias, resid, p, stream);   // 128 x 128
+    if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, in_scale, out_scale, bias, resid, p, stream);   // 128 x 64
+    return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, in_scale, out_scale, bias, resid, p, stream);                     // 128 x 32
+}
+
+int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                     const ideas_conv_params* p, hipStream_t stream) {
+    if (p->Cout > 64) return launch_bf16_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 128 (o) x 128 (k)
+    if (p->Cout > 32) return launch_bf16_wgrad_cfg<2, 2, 1, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 64 x 128
+    return launch_bf16_wgrad_cfg<1, 4, 1, 1>(gw, gy, x, in_scale, out_scale, p, stream);                     // 32 x 128
+}

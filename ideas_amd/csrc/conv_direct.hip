@@ -8,15 +8,28 @@
 
 namespace {
 
+// element access for the two activation dtypes (float, or bf16 stored as unsigned short): f32 arithmetic either way
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float ldv(const float* p) { return *p; }
+__device__ __forceinline__ float ldv(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stv(bf16_t* p, float v) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 t = {v, 0.f};
+    *p = (bf16_t)(__builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)) & 0xffffu);   // RNE
+}
+
 __device__ __forceinline__ bool in_coord(int& i, int n, int reflect) {
     if (reflect) { i = reflect_coord(i, n); return true; }
     return i >= 0 && i < n;
 }
 
-__global__ __launch_bounds__(256) void conv_direct_kernel(float* __restrict__ y, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                           const float* __restrict__ w, const float* __restrict__ in_scale,
                                                           const float* __restrict__ out_scale, const float* __restrict__ bias,
-                                                          const float* __restrict__ resid, ideas_conv_params p) {
+                                                          const T* __restrict__ resid, ideas_conv_params p) {
     const int64_t total = (int64_t)p.B * p.OH * p.OW * p.Cout;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int K = p.TY * p.TX * p.Cin;
@@ -34,13 +47,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(float* __restrict__ y,
             for (int tx = 0; tx < p.TX; ++tx) {
                 int ix = ox * p.sx + tx * p.dx + p.offx;
                 if (!in_coord(ix, p.IW, p.reflect)) continue;
-                const float* xp = x + (((int64_t)b * p.IH + iy) * p.IW + ix) * p.Cin;
+                const T* xp = x + (((int64_t)b * p.IH + iy) * p.IW + ix) * p.Cin;
                 const float* wp = wr + (ty * p.TX + tx) * p.Cin;
                 if (in_scale) {
                     const float* sp = in_scale + (int64_t)b * p.Cin;
-                    for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(xp[ci] * sp[ci], wp[ci], acc);
+                    for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(ldv(xp + ci) * sp[ci], wp[ci], acc);
                 } else {
-                    for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(xp[ci], wp[ci], acc);
+                    for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(ldv(xp + ci), wp[ci], acc);
                 }
             }
         }
@@ -49,14 +62,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(float* __restrict__ y,
         v = mul_then_add(v, 1.0f, bias ? bias[o] : 0.f);
         if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
         const int64_t yi = (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + o;
-        if (resid) v = (v + resid[yi]) * p.resid_gain;
-        if (p.accumulate) y[yi] += v; else y[yi] = v;
+        if (resid) v = (v + ldv(resid + yi)) * p.resid_gain;
+        if (p.accumulate) v += ldv(y + yi);
+        stv(y + yi, v);
     }
 }
 
 // gw[o][k] += sum_p G(p,o) * X(p,k): each block reduces a chunk of pixels for every (o,k) pair.
-__global__ __launch_bounds__(256) void wgrad_direct_kernel(float* __restrict__ gw, const float* __restrict__ gy,
-                                                           const float* __restrict__ x, const float* __restrict__ in_scale,
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(float* __restrict__ gw, const T* __restrict__ gy,
+                                                           const T* __restrict__ x, const float* __restrict__ in_scale,
                                                            const float* __restrict__ out_scale, ideas_conv_params p,
                                                            int64_t pix_per_block) {
     const int K = p.TY * p.TX * p.Cin;
@@ -80,9 +95,9 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(float* __restrict__ g
             int iy = oy * p.sy + ty * p.dy + p.offy;
             int ix = ox * p.sx + tx * p.dx + p.offx;
             if (!in_coord(iy, p.IH, p.reflect) || !in_coord(ix, p.IW, p.reflect)) continue;
-            float xv = x[(((int64_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci];
+            float xv = ldv(x + (((int64_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci);
             if (in_scale) xv *= in_scale[(int64_t)b * p.Cin + ci];
-            float g = gy[(((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + o];
+            float g = ldv(gy + (((int64_t)b * p.YH + (oy * p.osy + p.ooy)) * p.YW + (ox * p.osx + p.oox)) * p.Cout + o);
             if (out_scale) g *= out_scale[(int64_t)b * p.Cout + o];
             acc = fmaf(g, xv, acc);
         }
@@ -94,10 +109,10 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(float* __restrict__ g
 // The tiny-K layers on the path are all pointwise: from-RGB (3 -> 32/64), Gstru's N -> 32, to_rgb's input
 // gradient (3 -> 128), Ex's last layer.  A thread owns ONE output channel (weights in registers), walks pixels
 // with a fixed stride and writes coalesced along channels; x is a broadcast load.  Pure HBM streaming.
-template <int KMAX>
-__global__ __launch_bounds__(256) void pointwise_smallk_kernel(float* __restrict__ y, const float* __restrict__ x,
+template <int KMAX, typename T>
+__global__ __launch_bounds__(256) void pointwise_smallk_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                                const float* __restrict__ w, const float* __restrict__ bias,
-                                                               const float* __restrict__ resid, int64_t P, int Cin, int Cout,
+                                                               const T* __restrict__ resid, int64_t P, int Cin, int Cout,
                                                                float gain, int act, float alpha, float act_gain,
                                                                float resid_gain, int accumulate) {
     const int groups = blockDim.x / Cout;            // pixel lanes per block
@@ -109,24 +124,25 @@ __global__ __launch_bounds__(256) void pointwise_smallk_kernel(float* __restrict
     const float bv = bias ? bias[o] : 0.f;
     const int64_t stride = (int64_t)gridDim.x * groups;
     for (int64_t pp = (int64_t)blockIdx.x * groups + grp; pp < P; pp += stride) {
-        const float* xp = x + pp * Cin;
+        const T* xp = x + pp * Cin;
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < Cin) acc = fmaf(xp[k], wr[k], acc);
+            if (k < Cin) acc = fmaf(ldv(xp + k), wr[k], acc);
         float v = mul_then_add(acc, gain, bv);   // no FMA contraction: bitwise the unfused conv -> bias_act
         if (act) v = (v > 0.f ? v : v * alpha) * act_gain;
         const int64_t yi = pp * Cout + o;
-        if (resid) v = (v + resid[yi]) * resid_gain;
-        if (accumulate) y[yi] += v; else y[yi] = v;
+        if (resid) v = (v + ldv(resid + yi)) * resid_gain;
+        if (accumulate) v += ldv(y + yi);
+        stv(y + yi, v);
     }
 }
 
 // gw[o][ci] += gain * sum_p gy[p][o] * x[p][ci] with min(Cin, Cout) <= 8.  WIDE_OUT: threads span o (gy coalesced,
 // x broadcast, Cin accumulators); otherwise threads span ci (x coalesced, gy broadcast, Cout accumulators).
-template <int SMALL, bool WIDE_OUT>
-__global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
-                                                                    const float* __restrict__ x, int64_t P, int Cin, int Cout,
+template <int SMALL, bool WIDE_OUT, typename T>
+__global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __restrict__ gw, const T* __restrict__ gy,
+                                                                    const T* __restrict__ x, int64_t P, int Cin, int Cout,
                                                                     float gain, int64_t pix_per_block) {
     __shared__ float s_red[256 * 8];   // [wide][SMALL] block-level partial sums
     const int wide = WIDE_OUT ? Cout : Cin, small = WIDE_OUT ? Cin : Cout;
@@ -141,11 +157,11 @@ __global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __res
 #pragma unroll
         for (int k = 0; k < SMALL; ++k) acc[k] = 0.f;
         for (int64_t pp = p0 + grp; pp < p1; pp += groups) {
-            const float a = WIDE_OUT ? gy[pp * Cout + c] : x[pp * Cin + c];
-            const float* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
+            const float a = WIDE_OUT ? ldv(gy + pp * Cout + c) : ldv(x + pp * Cin + c);
+            const T* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
 #pragma unroll
             for (int k = 0; k < SMALL; ++k)
-                if (k < small) acc[k] = fmaf(a, bp[k], acc[k]);
+                if (k < small) acc[k] = fmaf(a, ldv(bp + k), acc[k]);
         }
 #pragma unroll
         for (int k = 0; k < SMALL; ++k)
@@ -176,42 +192,31 @@ int check_conv(const ideas_conv_params* p) {
     return IDEAS_OK;
 }
 
-}  // namespace
-
-extern "C" int ideas_conv_check_params(const ideas_conv_params* p) { return check_conv(p); }
-
-extern "C" int ideas_conv_direct(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
-                                 const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
-                                 void* stream) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
-    if (!y || !x || !wmat) return IDEAS_E_NULL;
-    int rc = check_conv(p);
-    if (rc) return rc;
+template <typename T>
+int conv_direct_impl(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale, const float* bias,
+                     const void* resid, const ideas_conv_params* p, void* stream) {
     if (is_pointwise(p) && !in_scale && !out_scale && p->Cin <= 8 && p->Cout <= 256) {
         const int64_t P = (int64_t)p->B * p->OH * p->OW;
         const int groups = 256 / p->Cout;
         int64_t grid = ideas_cdiv(P, (int64_t)groups * 8);
         if (grid > 8192) grid = 8192;
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL(pointwise_smallk_kernel<8>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float*)y,
-                           (const float*)x, (const float*)wmat, bias, (const float*)resid, P, p->Cin, p->Cout, p->gain,
-                           p->act, p->alpha, p->act_gain, p->resid_gain, p->accumulate);
+        hipLaunchKernelGGL((pointwise_smallk_kernel<8, T>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (T*)y,
+                           (const T*)x, (const float*)wmat, bias, (const T*)resid, P, p->Cin, p->Cout, p->gain, p->act, p->alpha,
+                           p->act_gain, p->resid_gain, p->accumulate);
         return ideas_launch_status();
     }
     const int64_t total = (int64_t)p->B * p->OH * p->OW * p->Cout;
     int64_t grid = ideas_cdiv(total, 256);
     if (grid > 65536) grid = 65536;
-    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float*)y,
-                       (const float*)x, (const float*)wmat, in_scale, out_scale, bias, (const float*)resid, *p);
+    hipLaunchKernelGGL(conv_direct_kernel<T>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (T*)y, (const T*)x,
+                       (const float*)wmat, in_scale, out_scale, bias, (const T*)resid, *p);
     return ideas_launch_status();
 }
 
-extern "C" int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x, const float* in_scale,
-                                       const float* out_scale, const ideas_conv_params* p, int dtype, void* stream) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
-    if (!gw || !gy || !x) return IDEAS_E_NULL;
-    int rc = check_conv(p);
-    if (rc) return rc;
+template <typename T>
+int wgrad_direct_impl(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                      const ideas_conv_params* p, void* stream) {
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
     if (is_pointwise(p) && !in_scale && !out_scale && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256) {
         int64_t blocks = ideas_cdiv(P, 512);
@@ -219,18 +224,50 @@ extern "C" int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x,
         const int64_t per = ideas_cdiv(P, blocks);
         blocks = ideas_cdiv(P, per);
         if (p->Cin <= 8 && p->Cin <= p->Cout)
-            hipLaunchKernelGGL((pointwise_small_wgrad_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0,
-                               (hipStream_t)stream, gw, (const float*)gy, (const float*)x, P, p->Cin, p->Cout, p->gain, per);
+            hipLaunchKernelGGL((pointwise_small_wgrad_kernel<8, true, T>), dim3((unsigned)blocks), dim3(256), 0,
+                               (hipStream_t)stream, gw, (const T*)gy, (const T*)x, P, p->Cin, p->Cout, p->gain, per);
         else
-            hipLaunchKernelGGL((pointwise_small_wgrad_kernel<8, false>), dim3((unsigned)blocks), dim3(256), 0,
-                               (hipStream_t)stream, gw, (const float*)gy, (const float*)x, P, p->Cin, p->Cout, p->gain, per);
+            hipLaunchKernelGGL((pointwise_small_wgrad_kernel<8, false, T>), dim3((unsigned)blocks), dim3(256), 0,
+                               (hipStream_t)stream, gw, (const T*)gy, (const T*)x, P, p->Cin, p->Cout, p->gain, per);
         return ideas_launch_status();
     }
     int64_t blocks = ideas_cdiv(P, 256);
     if (blocks > 2048) blocks = 2048;
     const int64_t per = ideas_cdiv(P, blocks);
     blocks = ideas_cdiv(P, per);
-    hipLaunchKernelGGL(wgrad_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw,
-                       (const float*)gy, (const float*)x, in_scale, out_scale, *p, per);
+    hipLaunchKernelGGL(wgrad_direct_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const T*)gy,
+                       (const T*)x, in_scale, out_scale, *p, per);
     return ideas_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ideas_conv_check_params(const ideas_conv_params* p) { return check_conv(p); }
+
+/* 1 if the VALU kernels are the intended bf16 path for this geometry (the HBM-bound tiny-K / tiny-N layers: from-RGB, to-RGB
+ * and their gradients); everything else without an MFMA bf16 kernel is computed in f32 by the caller. */
+extern "C" int ideas_bf16_direct_supported(const ideas_conv_params* p) {
+    if (!p || check_conv(p)) return 0;
+    return is_pointwise(p) && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256;
+}
+
+extern "C" int ideas_conv_direct(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
+                                 const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
+                                 void* stream) {
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
+    if (!y || !x || !wmat) return IDEAS_E_NULL;
+    int rc = check_conv(p);
+    if (rc) return rc;
+    if (dtype == IDEAS_BF16) return conv_direct_impl<bf16_t>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);
+    return conv_direct_impl<float>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);
+}
+
+extern "C" int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x, const float* in_scale,
+                                       const float* out_scale, const ideas_conv_params* p, int dtype, void* stream) {
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
+    if (!gw || !gy || !x) return IDEAS_E_NULL;
+    int rc = check_conv(p);
+    if (rc) return rc;
+    if (dtype == IDEAS_BF16) return wgrad_direct_impl<bf16_t>(gw, gy, x, in_scale, out_scale, p, stream);
+    return wgrad_direct_impl<float>(gw, gy, x, in_scale, out_scale, p, stream);
 }

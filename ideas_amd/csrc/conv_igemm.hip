@@ -573,10 +573,17 @@ int launch_wgrad_cfg(float* gw, const void* gy, const void* x, const float* in_s
 extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
                                 const float* bias, const void* resid, const ideas_conv_params* p, int dtype,
                                 void* stream_) {
-    if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!y || !x || !wmat) return IDEAS_E_NULL;
     int rc = check_conv(p);
     if (rc) return rc;
+    if (dtype == IDEAS_BF16) {     // bf16 x / y / resid, wmat = pack of ideas_bf16_pack_weights, f32 scales and bias
+        if (!ideas_bf16_conv_supported(p, in_scale != nullptr)) return IDEAS_E_UNSUPPORTED;
+        if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || !ideas_aligned16(y) || (in_scale && !ideas_aligned16(in_scale)) ||
+            (out_scale && !ideas_aligned16(out_scale)) || (bias && !ideas_aligned16(bias)) || (resid && !ideas_aligned16(resid)))
+            return IDEAS_E_ALIGN;
+        return ideas_bf16_fwd(y, x, wmat, in_scale, out_scale, bias, resid, p, (hipStream_t)stream_);
+    }
     if (p->Cin % 4) return IDEAS_E_ALIGN;
     if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
     hipStream_t stream = (hipStream_t)stream_;
@@ -591,12 +598,17 @@ extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const 
 
 extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                                 const ideas_conv_params* p, int dtype, void* stream_) {
-    if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!gw || !gy || !x) return IDEAS_E_NULL;
     int rc = check_conv(p);
     if (rc) return rc;
     if (p->Cin % 4 || p->Cout % 4) return IDEAS_E_ALIGN;
     if ((in_scale == nullptr) != (out_scale == nullptr)) return IDEAS_E_UNSUPPORTED;  // both or neither
+    if (dtype == IDEAS_BF16) {     // bf16 gy / x, f32 gw and scales
+        if (!ideas_bf16_wgrad_supported(p, in_scale != nullptr)) return IDEAS_E_UNSUPPORTED;
+        if (!ideas_aligned16(x) || !ideas_aligned16(gy)) return IDEAS_E_ALIGN;
+        return ideas_bf16_wgrad(gw, gy, x, in_scale, out_scale, p, (hipStream_t)stream_);
+    }
     if (!ideas_aligned16(x) || !ideas_aligned16(gy) || (in_scale && !ideas_aligned16(in_scale)) ||
         (out_scale && !ideas_aligned16(out_scale)))
         return IDEAS_E_ALIGN;

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const
     if (lane == 0) d[idx] = rsqrtf(acc + eps);
 }
 
-__global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out, const float* __restrict__ a,
-                                                        const float* __restrict__ g, int64_t P, int C,
+template <typename T, typename V>      // T = element (float / bf16), V = four consecutive elements
+__global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out, const T* __restrict__ a,
+                                                        const T* __restrict__ g, int64_t P, int C,
                                                         int64_t pix_per_block) {
     extern __shared__ float s_acc[];
     const int b = blockIdx.y;
@@ -33,15 +34,15 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out,
     const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
     for (int c = threadIdx.x; c < C; c += blockDim.x) s_acc[c] = 0.f;
     __syncthreads();
-    const float* ab = a + (int64_t)b * P * C;
-    const float* gb = g + (int64_t)b * P * C;
+    const T* ab = a + (int64_t)b * P * C;
+    const T* gb = g + (int64_t)b * P * C;
     if ((C & 3) == 0) {
         const int C4 = C >> 2;
         auto dot_rows = [&](int c4, int pr, int R) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int64_t pp = p0 + pr; pp < p1; pp += R) {
-                const float4 av = *reinterpret_cast<const float4*>(ab + pp * C + c4 * 4);
-                const float4 gv = *reinterpret_cast<const float4*>(gb + pp * C + c4 * 4);
+                const float4 av = to_f4(*reinterpret_cast<const V*>(ab + pp * C + c4 * 4));
+                const float4 gv = to_f4(*reinterpret_cast<const V*>(gb + pp * C + c4 * 4));
                 acc.x = fmaf(av.x, gv.x, acc.x); acc.y = fmaf(av.y, gv.y, acc.y);
                 acc.z = fmaf(av.z, gv.z, acc.z); acc.w = fmaf(av.w, gv.w, acc.w);
             }
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out,
         }
     } else {
         for (int64_t i = p0 * C + threadIdx.x; i < p1 * C; i += blockDim.x)
-            atomicAdd(&s_acc[(int)(i % C)], ab[i] * gb[i]);
+            atomicAdd(&s_acc[(int)(i % C)], ld1(ab + i) * ld1(gb + i));
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(int64_t)b * C + c], s_acc[c]);
@@ -69,11 +70,12 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out,
 //   bgrad[c]   += sum_{b,p} g_pre
 //   dot[b,c]   += sum_p g_pre * pre,   pre = inverse_act(out) - bias[c]   (= demodulated conv output)
 // so the pre-activation tensor never has to be kept for the backward (d(demod) = dot / demod).
-__global__ __launch_bounds__(256) void act_bwd_dot_kernel(float* __restrict__ gpre, float* __restrict__ bgrad,
-                                                          float* __restrict__ dot, const float* __restrict__ gy,
-                                                          const float* __restrict__ out, const float* __restrict__ bias,
-                                                          int64_t P, int C, int64_t pix_per_block, float alpha,
-                                                          float act_gain) {
+template <typename T, typename V>
+__global__ __launch_bounds__(256) void act_bwd_dot_kernel(T* __restrict__ gpre, float* __restrict__ bgrad,
+                                                          float* __restrict__ dot, const T* __restrict__ gy,
+                                                          const T* __restrict__ out, const float* __restrict__ bias,
+                                                          const float* __restrict__ gscale, int64_t P, int C,
+                                                          int64_t pix_per_block, float alpha, float act_gain) {
     extern __shared__ float s_acc[];   // [2][C]: dot partials, bias-grad partials
     const int b = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
@@ -86,10 +88,13 @@ __global__ __launch_bounds__(256) void act_bwd_dot_kernel(float* __restrict__ gp
     auto rows = [&](int c4, int pr, int R) {
         float4 accd = make_float4(0.f, 0.f, 0.f, 0.f), accb = accd;
         const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // optional per-(b, c) factor on the stored gradient only (bf16 path: the demodulation d[b,c], so that the input- and
+        // weight-gradient kernels need no per-sample input scale); bias_grad / dot are taken before it
+        const float4 gs = gscale ? *reinterpret_cast<const float4*>(gscale + (int64_t)b * C + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         for (int64_t pp = p0 + pr; pp < p1; pp += R) {
             const int64_t off = base + pp * C + c4 * 4;
-            const float4 g = *reinterpret_cast<const float4*>(gy + off);
-            const float4 o = *reinterpret_cast<const float4*>(out + off);
+            const float4 g = to_f4(*reinterpret_cast<const V*>(gy + off));
+            const float4 o = to_f4(*reinterpret_cast<const V*>(out + off));
             float4 gp;
 #define ONE(f)                                                                    \
     {                                                                             \
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void act_bwd_dot_kernel(float* __restrict__ gp
     }
             ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
-            *reinterpret_cast<float4*>(gpre + off) = gp;
+            *reinterpret_cast<V*>(gpre + off) = from_f4<V>(make_float4(gp.x * gs.x, gp.y * gs.y, gp.z * gs.z, gp.w * gs.w));
         }
         atomicAdd(&s_acc[c4 * 4 + 0], accd.x); atomicAdd(&s_acc[c4 * 4 + 1], accd.y);
         atomicAdd(&s_acc[c4 * 4 + 2], accd.z); atomicAdd(&s_acc[c4 * 4 + 3], accd.w);
@@ -137,25 +142,30 @@ extern "C" int ideas_demod(float* d, const float* s, const float* wsq, int B, in
 
 extern "C" int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, int C, int dtype,
                                void* stream) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!out || !a || !g) return IDEAS_E_NULL;
     if (B <= 0 || P <= 0 || C <= 0 || C > 12288 || B > 65535) return IDEAS_E_SHAPE;
     if ((C & 3) == 0 && (!ideas_aligned16(a) || !ideas_aligned16(g))) return IDEAS_E_ALIGN;
+    if (dtype == IDEAS_BF16 && (C & 3)) return IDEAS_E_ALIGN;
     int64_t chunks = ideas_cdiv(2048, B);
     const int64_t max_chunks = ideas_cdiv(P, 64);
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     const int64_t per = ideas_cdiv(P, chunks);
     chunks = ideas_cdiv(P, per);
-    hipLaunchKernelGGL(pixel_dot_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), (size_t)C * sizeof(float),
-                       (hipStream_t)stream, out, (const float*)a, (const float*)g, P, C, per);
+    if (dtype == IDEAS_BF16)
+        hipLaunchKernelGGL((pixel_dot_kernel<ideas_bf16, ideas_bf16x4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
+                           (size_t)C * sizeof(float), (hipStream_t)stream, out, (const ideas_bf16*)a, (const ideas_bf16*)g, P, C, per);
+    else
+        hipLaunchKernelGGL((pixel_dot_kernel<float, float4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
+                           (size_t)C * sizeof(float), (hipStream_t)stream, out, (const float*)a, (const float*)g, P, C, per);
     return ideas_launch_status();
 }
 
 extern "C" int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out,
-                                 const float* bias, int B, int64_t P, int C, float alpha, float act_gain, int dtype,
-                                 void* stream) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+                                 const float* bias, const float* gpre_scale, int B, int64_t P, int C, float alpha,
+                                 float act_gain, int dtype, void* stream) {
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!gpre || !bias_grad || !dot || !gy || !out) return IDEAS_E_NULL;
     if (B <= 0 || P <= 0 || C <= 0 || C > 6144 || B > 65535) return IDEAS_E_SHAPE;
     if (C & 3) return IDEAS_E_ALIGN;
@@ -167,8 +177,13 @@ extern "C" int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const
     if (chunks < 1) chunks = 1;
     const int64_t per = ideas_cdiv(P, chunks);
     chunks = ideas_cdiv(P, per);
-    hipLaunchKernelGGL(act_bwd_dot_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), (size_t)2 * C * sizeof(float),
-                       (hipStream_t)stream, (float*)gpre, bias_grad, dot, (const float*)gy, (const float*)out, bias, P, C,
-                       per, alpha, act_gain);
+    if (dtype == IDEAS_BF16)
+        hipLaunchKernelGGL((act_bwd_dot_kernel<ideas_bf16, ideas_bf16x4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
+                           (size_t)2 * C * sizeof(float), (hipStream_t)stream, (ideas_bf16*)gpre, bias_grad, dot,
+                           (const ideas_bf16*)gy, (const ideas_bf16*)out, bias, gpre_scale, P, C, per, alpha, act_gain);
+    else
+        hipLaunchKernelGGL((act_bwd_dot_kernel<float, float4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
+                           (size_t)2 * C * sizeof(float), (hipStream_t)stream, (float*)gpre, bias_grad, dot, (const float*)gy,
+                           (const float*)out, bias, gpre_scale, P, C, per, alpha, act_gain);
     return ideas_launch_status();
 }

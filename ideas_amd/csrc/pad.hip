@@ -6,11 +6,17 @@
 namespace {
 
 __device__ __forceinline__ void acc_add(float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+__device__ __forceinline__ void acc_add(float4& a, const ideas_bf16x4& v) { acc_add(a, to_f4(v)); }
 __device__ __forceinline__ void acc_add(float& a, const float& v) { a += v; }
 __device__ __forceinline__ void acc_zero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void acc_zero(float& a) { a = 0.f; }
+template <typename V> struct AccOf { typedef V type; };
+template <> struct AccOf<ideas_bf16x4> { typedef float4 type; };
+__device__ __forceinline__ float4 acc_out(float4 a, float4*) { return a; }
+__device__ __forceinline__ float acc_out(float a, float*) { return a; }
+__device__ __forceinline__ ideas_bf16x4 acc_out(float4 a, ideas_bf16x4*) { return from_f4<ideas_bf16x4>(a); }
 
-// V = float4 (C % 4 == 0, C4 = C / 4) or float (any C, C4 = C)
+// V = float4 / ideas_bf16x4 (C % 4 == 0, C4 = C / 4) or float (any C, C4 = C)
 template <typename V>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(V* __restrict__ gx, const V* __restrict__ gp, int B,
                                                            int H, int W, int C4, int pad) {
@@ -30,11 +36,11 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(V* __restrict__ gx, c
         xs[nx++] = x + pad;
         if (x >= 1 && x <= pad) xs[nx++] = pad - x;
         if (x >= W - 1 - pad && x <= W - 2) xs[nx++] = 2 * (W - 1) + pad - x;
-        V acc;
+        typename AccOf<V>::type acc;
         acc_zero(acc);
         for (int a = 0; a < ny; ++a)
             for (int e = 0; e < nx; ++e) acc_add(acc, gp[(((int64_t)b * Hp + ys[a]) * Wp + xs[e]) * C4 + c]);
-        gx[i] = acc;
+        gx[i] = acc_out(acc, (V*)nullptr);
     }
 }
 
@@ -42,15 +48,19 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(V* __restrict__ gx, c
 
 extern "C" int ideas_reflect_fold(void* gx, const void* gpadded, int B, int H, int W, int C, int pad, int dtype,
                                   void* stream) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!gx || !gpadded) return IDEAS_E_NULL;
+    if (dtype == IDEAS_BF16 && (C & 3)) return IDEAS_E_ALIGN;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad <= 0 || pad >= H || pad >= W) return IDEAS_E_SHAPE;
     const bool vec = !(C & 3) && ideas_aligned16(gx) && ideas_aligned16(gpadded);
     const int C4 = vec ? C / 4 : C;
     const int64_t total = (int64_t)B * H * W * C4;
     int64_t grid = ideas_cdiv(total, 256);
     if (grid > 16384) grid = 16384;
-    if (vec)
+    if (dtype == IDEAS_BF16)
+        hipLaunchKernelGGL(reflect_fold_kernel<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                           (ideas_bf16x4*)gx, (const ideas_bf16x4*)gpadded, B, H, W, C4, pad);
+    else if (vec)
         hipLaunchKernelGGL(reflect_fold_kernel<float4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (float4*)gx,
                            (const float4*)gpadded, B, H, W, C4, pad);
     else   // channel counts that are not a multiple of 4 (the N-channel / RGB ends of Gstru, Ex, E): scalar path

@@ -21,8 +21,8 @@ struct FirParams {
 };
 
 // ---------------- generic: out[oy,ox] = sum_k U[oy*down + ky - pad0] * Kf[ky] ----------------------
-template <bool NHWC>
-__global__ __launch_bounds__(256) void upfirdn2d_generic(float* __restrict__ y, const float* __restrict__ x,
+template <bool NHWC, typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic(T* __restrict__ y, const T* __restrict__ x,
                                                          const float* __restrict__ fir, FirParams p) {
     __shared__ float sk[64];
     for (int t = threadIdx.x; t < p.kh * p.kw; t += blockDim.x) {
@@ -58,16 +58,17 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(float* __restrict__ y, 
                 if (ix >= p.in_w) continue;
                 int64_t src = NHWC ? (((int64_t)b * p.in_h + iy) * p.in_w + ix) * p.C + c
                                    : (((int64_t)b * p.C + c) * p.in_h + iy) * p.in_w + ix;
-                acc += x[src] * sk[ky * p.kw + kx];
+                acc += ld1(x + src) * sk[ky * p.kw + kx];
             }
         }
-        y[i] = acc;
+        st1(y + i, acc);
     }
 }
 
 // ---------------- NHWC 4x4 blur, up = down = 1 ---------------------------------------------------
 // thread = (b, row-segment, ox, c4); window w[r][t] holds input rows iy0..iy0+3 at columns ix0..ix0+3
-__global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const float4* __restrict__ x,
+template <typename V>
+__global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __restrict__ x,
                                                   const float* __restrict__ fir, FirParams p) {
     __shared__ float sk[16];
     if (threadIdx.x < 16) {
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const 
     for (int t = 0; t < 16; ++t) k[t] = sk[t];
 
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
+    const V* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
     unsigned colmask = 0;   // bit t: column ix0+t is inside the image (a bool[4] ends up in scratch memory)
 #pragma unroll
     for (int t = 0; t < 4; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
@@ -102,11 +103,11 @@ __global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const 
     float4 w[4][4];
     auto load_row = [&](int iy, float4 (&dst)[4]) {
         const bool rowok = (iy >= 0) && (iy < p.in_h);
-        const float4* xr = xb + ((int64_t)iy * p.in_w + ix0) * C4;
+        const V* xr = xb + ((int64_t)iy * p.in_w + ix0) * C4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float4 v = zero;
-            if (rowok && ((colmask >> t) & 1u)) v = xr[(int64_t)t * C4];
+            if (rowok && ((colmask >> t) & 1u)) v = to_f4(xr[(int64_t)t * C4]);
             dst[t] = v;
         }
     };
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const 
     load_row(iy0 + 0, w[0]);
     load_row(iy0 + 1, w[1]);
     load_row(iy0 + 2, w[2]);
-    float4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    V* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
     auto emit = [&](int oy, const float4 (&r0)[4], const float4 (&r1)[4], const float4 (&r2)[4], const float4 (&r3)[4]) {
         float4 acc = zero;
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void blur4_nhwc(float4* __restrict__ y, const 
             acc.z += r0[t].z * k0 + r1[t].z * k1 + r2[t].z * k2 + r3[t].z * k3;
             acc.w += r0[t].w * k0 + r1[t].w * k1 + r2[t].w * k2 + r3[t].w * k3;
         }
-        yb[(int64_t)oy * p.out_w * C4] = acc;
+        yb[(int64_t)oy * p.out_w * C4] = from_f4<V>(acc);
     };
     // two output rows per trip: 8 independent 16-byte loads in flight instead of 4 (the window shift is a
     // dependent chain, so one row per trip is latency-bound)
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(256) void blur_nchw_tile(float* __restrict__ y, con
 extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h,
                                int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                                int pad_y0, float gain, int flip, int layout, int dtype, void* stream_) {
-    if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
+    if (dtype == IDEAS_BF16 && layout != IDEAS_NHWC) return IDEAS_E_UNSUPPORTED;
     if (!y || !x || !fir) return IDEAS_E_NULL;
     if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return IDEAS_E_SHAPE;
     if (kh <= 0 || kw <= 0 || kh > 8 || kw > 8) return IDEAS_E_UNSUPPORTED;
@@ -214,7 +216,11 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
         const int64_t total = (int64_t)B * segs * out_w * (C / 4);
         const int64_t grid = ideas_cdiv(total, 256);
         if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
-        hipLaunchKernelGGL(blur4_nhwc, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
+        if (dtype == IDEAS_BF16)
+            hipLaunchKernelGGL(blur4_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
+                               (const ideas_bf16x4*)x, fir, p);
+        else
+            hipLaunchKernelGGL(blur4_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
         return ideas_launch_status();
     }
     if (unit && layout == IDEAS_NCHW && kh <= 4 && kw <= 4) {
@@ -226,11 +232,14 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
     const int64_t total = (int64_t)B * C * out_h * out_w;
     int64_t grid = ideas_cdiv(total, 256);
     if (grid > 65536) grid = 65536;
-    if (layout == IDEAS_NHWC)
-        hipLaunchKernelGGL(upfirdn2d_generic<true>, dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
+    if (dtype == IDEAS_BF16)
+        hipLaunchKernelGGL((upfirdn2d_generic<true, ideas_bf16>), dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16*)y,
+                           (const ideas_bf16*)x, fir, p);
+    else if (layout == IDEAS_NHWC)
+        hipLaunchKernelGGL((upfirdn2d_generic<true, float>), dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
                            (const float*)x, fir, p);
     else
-        hipLaunchKernelGGL(upfirdn2d_generic<false>, dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
+        hipLaunchKernelGGL((upfirdn2d_generic<false, float>), dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
                            (const float*)x, fir, p);
     return ideas_launch_status();
 }

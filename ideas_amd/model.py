@@ -96,7 +96,7 @@ class EqualLinear(nn.Module):
     def forward(self, input):
         # (x * scale) @ W^T instead of x @ (W * scale)^T (stylegan2/model.py:152-160): the same product re-associated, with
         # the [B, in] activation scaled instead of the [out, in] weight (and no scaled-weight pass in the backward either)
-        x = input * self.scale
+        x = (input if input.dtype == torch.float32 else input.float()) * self.scale       # linear layers are f32 in every mode
         b = self.bias if (self.bias is None or self.lr_mul == 1) else self.bias * self.lr_mul
         if self.activation:
             return fused_leaky_relu(F.linear(x, self.weight), b)

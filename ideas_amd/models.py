@@ -21,6 +21,7 @@ from torch import nn
 from .model import (CL, Blur, EqualConv2d, EqualLinear, ScaledLeakyReLU,
                     StyledConv_without_noise as StyledConv)
 from .op import FusedLeakyReLU, conv_transpose2d
+from .precision import to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
 
@@ -193,7 +194,7 @@ class DisentanglementEncoder(nn.Module):
 
     def forward(self, input):
         feat = self.stem(input)
-        return self.structure(feat), torch.flatten(self.texture(feat), 1)
+        return to_f32(self.structure(feat)), to_f32(torch.flatten(self.texture(feat), 1))
 
 
 class Generator(nn.Module):
@@ -215,7 +216,7 @@ class Generator(nn.Module):
         out = structure
         for layer in self.layers:
             out = layer(out, texture, None)
-        return self.to_rgb(out)
+        return to_f32(self.to_rgb(out))
 
 
 class StructureGenerator(nn.Module):
@@ -233,7 +234,7 @@ class StructureGenerator(nn.Module):
         )
 
     def forward(self, noise):
-        return self.structure(noise)
+        return to_f32(self.structure(noise))
 
 
 class ImageLevelDiscriminator(nn.Module):
@@ -327,7 +328,7 @@ class TensorExtractor(nn.Module):
         )
 
     def forward(self, input):
-        return self.extract(input)
+        return to_f32(self.extract(input))
 
 
 _FACTORY = {

@@ -18,6 +18,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
+from ..precision import to_act
 from . import conv_plan
 from .conv_plan import ConvGeom, Launch, convT_out_size, plan_dgrad, plan_fwd, plan_wgrad
 
@@ -80,9 +81,28 @@ def launch_wino(y, x, umat, b, cin, h, w, cout, gain, reflect, in_scale=None, ou
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"ideas_amd conv: only float32 is implemented, got {t.dtype}")
+    if t.dtype != torch.float32 and t.dtype != torch.bfloat16:
+        raise RuntimeError(f"ideas_amd conv: only float32 and bfloat16 activations are implemented, got {t.dtype}")
     return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+BF = torch.bfloat16
+
+
+def _f32(t):
+    return None if t is None else t.float()
+
+
+def bf16_pack(L: Launch, w: torch.Tensor) -> torch.Tensor:
+    """bf16 pack of a forward-family weight matrix for ideas_conv_igemm(IDEAS_BF16), memoised like the b3 planes."""
+    k = L.TY * L.TX * L.Cin
+
+    def make():
+        pk = torch.empty(L.Cout * k, device=w.device, dtype=BF)
+        _lib.check(_lib.load().ideas_bf16_pack_weights(_lib.ptr(pk), _lib.ptr(w), L.Cout, k, L.Cin, _lib.stream_ptr()),
+                   "ideas_bf16_pack_weights")
+        return pk
+    return conv_plan.cached(L.wsrc, ("bf16",) + L.wkey, make) if L.wsrc is not None else make()
 
 
 def _params(L: Launch, gain: float, accumulate: bool = False, act: bool = False, alpha: float = 0.2,
@@ -101,6 +121,23 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
     w = L.wmat
     if not w.is_contiguous():
         w = w.contiguous()
+    if x.dtype == BF:
+        if lib.ideas_bf16_conv_supported(C.byref(p), int(in_scale is not None)):
+            rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bf16_pack(L, w)), _lib.ptr(in_scale), _lib.ptr(out_scale),
+                                      _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.BF16, _lib.stream_ptr())
+            _lib.check(rc, "ideas_conv_igemm[bf16]")
+            return
+        if lib.ideas_bf16_direct_supported(C.byref(p)) and in_scale is None and out_scale is None:
+            rc = lib.ideas_conv_direct(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(bias), _lib.ptr(resid),
+                                       C.byref(p), _lib.BF16, _lib.stream_ptr())
+            _lib.check(rc, "ideas_conv_direct[bf16]")
+            return
+        # geometries without a bf16 kernel (tiny layers: N-channel / 8-channel ends, odd sizes): f32 kernels on casts
+        partial = L.osy != 1 or L.osx != 1 or L.OH != L.YH or L.OW != L.YW     # a parity phase writes only its own pixels
+        y32 = y.float() if (accumulate or partial) else torch.empty(y.shape, device=y.device, dtype=torch.float32, memory_format=CL)
+        launch_fwd(y32, x.float(), L, gain, in_scale, out_scale, bias, _f32(resid), act, alpha, act_gain, resid_gain, accumulate)
+        y.copy_(y32)
+        return
     if MATH == _lib.F32_B3 and lib.ideas_b3_conv_supported(C.byref(p)):
         k = L.TY * L.TX * L.Cin
 
@@ -124,6 +161,18 @@ def launch_wgrad(gw: torch.Tensor, gy: torch.Tensor, x: torch.Tensor, L: Launch,
                  out_scale=None) -> None:
     lib = _lib.load()
     p = _params(L, gain)
+    if x.dtype == BF:
+        if lib.ideas_bf16_wgrad_supported(C.byref(p), int(in_scale is not None)) and L.Cout > 8 and L.Cin > 8:
+            rc = lib.ideas_conv_wgrad(_lib.ptr(gw), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(out_scale), C.byref(p),
+                                      _lib.BF16, _lib.stream_ptr())
+            _lib.check(rc, "ideas_conv_wgrad[bf16]")
+            return
+        if lib.ideas_bf16_direct_supported(C.byref(p)) and in_scale is None and out_scale is None:
+            rc = lib.ideas_conv_wgrad_direct(_lib.ptr(gw), _lib.ptr(gy), _lib.ptr(x), None, None, C.byref(p), _lib.BF16,
+                                             _lib.stream_ptr())
+            _lib.check(rc, "ideas_conv_wgrad_direct[bf16]")
+            return
+        return launch_wgrad(gw, gy.float(), x.float(), L, gain, in_scale, out_scale)
     mfma = (L.Cin % 4 == 0) and (L.Cout % 4 == 0)
     fn = lib.ideas_conv_wgrad if mfma else lib.ideas_conv_wgrad_direct
     rc = fn(_lib.ptr(gw), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(in_scale), _lib.ptr(out_scale), C.byref(p),
@@ -141,14 +190,14 @@ def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None,
     x = _nhwc(x)
     if resid is not None:
         resid = _nhwc(resid)
-    if _b3_wino_ok(g, x.shape[1], w.shape[0], x.shape[3]):
+    if x.dtype == torch.float32 and _b3_wino_ok(g, x.shape[1], w.shape[0], x.shape[3]):
         b, ci, h, wd = x.shape
         co = w.shape[0]
         y = torch.empty((b, co, h, wd), device=x.device, dtype=x.dtype, memory_format=CL)
         launch_wino(y, x, b3_wino_planes(w, False), b, ci, h, wd, co, gain, g.reflect, lin, lout, bias, resid, act=act,
                     alpha=alpha, act_gain=act_gain, resid_gain=resid_gain, dtype=_lib.F32_B3)
         return y
-    if _wino_ok(g, x.shape[1], x.shape[3]):
+    if x.dtype == torch.float32 and _wino_ok(g, x.shape[1], x.shape[3]):
         b, ci, h, wd = x.shape
         co = w.shape[0]
         y = torch.empty((b, co, h, wd), device=x.device, dtype=x.dtype, memory_format=CL)
@@ -171,17 +220,20 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
         gxp = conv_dgrad_raw(gy, w, gp, (ph, pw), gain, lin, lout)
         b, c = gxp.shape[0], gxp.shape[1]
         gx = torch.empty((b, c, in_hw[0], in_hw[1]), device=gxp.device, dtype=gxp.dtype, memory_format=CL)
-        rc = _lib.load().ideas_reflect_fold(_lib.ptr(gx), _lib.ptr(gxp), b, in_hw[0], in_hw[1], c, g.pad, _lib.F32,
+        if gxp.dtype == BF and c % 4:
+            return conv_dgrad_fold32(gxp, in_hw, g.pad)
+        rc = _lib.load().ideas_reflect_fold(_lib.ptr(gx), _lib.ptr(gxp), b, in_hw[0], in_hw[1], c, g.pad, _lib.act_dtype(gxp),
                                             _lib.stream_ptr())
         _lib.check(rc, "ideas_reflect_fold")
         return gx
-    if in_hw == (gy.shape[2], gy.shape[3]) and _b3_wino_ok(g, gy.shape[1], w.shape[1], gy.shape[3]):
+    f32 = gy.dtype == torch.float32
+    if f32 and in_hw == (gy.shape[2], gy.shape[3]) and _b3_wino_ok(g, gy.shape[1], w.shape[1], gy.shape[3]):
         b, co, h, wd = gy.shape
         ci = w.shape[1]
         gx = torch.empty((b, ci, h, wd), device=gy.device, dtype=gy.dtype, memory_format=CL)
         launch_wino(gx, gy, b3_wino_planes(w, True), b, co, h, wd, ci, gain, False, lin, lout, dtype=_lib.F32_B3)
         return gx
-    if in_hw == (gy.shape[2], gy.shape[3]) and _wino_ok(g, gy.shape[1], gy.shape[3]):
+    if f32 and in_hw == (gy.shape[2], gy.shape[3]) and _wino_ok(g, gy.shape[1], gy.shape[3]):
         # dgrad of a 3x3/s1/p1 conv = the same conv with the taps flipped and the channel roles swapped
         b, co, h, wd = gy.shape
         ci = w.shape[1]
@@ -199,18 +251,30 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
     return gx
 
 
+def conv_dgrad_fold32(gxp: torch.Tensor, in_hw, pad: int) -> torch.Tensor:
+    """bf16 reflect fold for channel counts without a bf16 kernel (C % 4 != 0: the N-channel / RGB ends): f32 kernel on a cast."""
+    g32 = gxp.float()
+    b, c = g32.shape[0], g32.shape[1]
+    gx = torch.empty((b, c, in_hw[0], in_hw[1]), device=g32.device, dtype=torch.float32, memory_format=CL)
+    rc = _lib.load().ideas_reflect_fold(_lib.ptr(gx), _lib.ptr(g32), b, in_hw[0], in_hw[1], c, pad, _lib.F32, _lib.stream_ptr())
+    _lib.check(rc, "ideas_reflect_fold")
+    return gx.to(BF)
+
+
 def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None, out=None):
     """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy.
     ``out`` (an OHWI-contiguous tensor of that shape): ADD the gradient to it instead of returning a new tensor — the
     split-K kernels accumulate with atomics anyway, so this costs neither a zero-fill nor an add pass."""
     gy, x = _nhwc(gy), _nhwc(x)
+    if gy.dtype != x.dtype:               # (double-backward corner: a f32 cotangent meeting a bf16 activation)
+        gy, x = gy.float(), x.float()
     if (lin is None) != (lout is None):   # the MFMA wgrad kernels take both per-sample scales or neither
         if lin is None:
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
     L = plan_wgrad(x.shape, gy.shape, g)
-    b3 = MATH == _lib.F32_B3 and bool(_lib.load().ideas_b3_wgrad_supported(C.byref(_params(L, gain))))
+    b3 = x.dtype == BF or (MATH == _lib.F32_B3 and bool(_lib.load().ideas_b3_wgrad_supported(C.byref(_params(L, gain)))))
     if not b3 and _wino_ok(g, x.shape[1], x.shape[3], fwd=False) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
         b, ci, h, wd = x.shape
         co = gy.shape[1]
@@ -380,7 +444,7 @@ def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     """``gain * F.conv2d(input, weight, stride, padding) + bias`` (zero padding, or mirror padding if ``reflect``)."""
     _lib.require_cuda(input, weight, bias)
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
-    y = _Conv.apply(input, weight, g, float(gain))
+    y = _Conv.apply(to_act(input), weight, g, float(gain))
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y
@@ -419,7 +483,9 @@ def conv2d_bias_act(input: torch.Tensor, weight: torch.Tensor, act_bias: torch.T
     ``resid`` (inference only): the residual branch, added in the same epilogue."""
     _lib.require_cuda(input, weight, act_bias)
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
+    input = to_act(input)
     if resid is not None:
+        resid = to_act(resid)
         if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or act_bias.requires_grad or resid.requires_grad):
             raise RuntimeError("conv2d_bias_act(resid=...) is the no-grad fast path")
         return conv_fwd_raw(input, weight, g, float(gain), bias=act_bias.contiguous(), act=True, act_gain=float(scale),
@@ -453,7 +519,7 @@ def conv_transpose2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[t
     """``gain * F.conv_transpose2d(input, weight, stride=stride, padding=0) + bias``."""
     _lib.require_cuda(input, weight, bias)
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, 0, False)
-    y = _ConvT.apply(input, weight, g, float(gain))
+    y = _ConvT.apply(to_act(input), weight, g, float(gain))
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)
     return y

@@ -43,18 +43,27 @@ def bias_act_raw(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[to
                  alpha: float, scale: float, want_bias_grad: bool = False, act: int = 3):
     """One launch of ``ideas_fused_bias_act``; returns ``y`` or ``(y, bias_grad)``."""
     _lib.require_cuda(x, bias, ref)
-    if x.dtype != torch.float32:
-        raise RuntimeError(f"fused_bias_act: only float32 is implemented, got {x.dtype}")
+    dt = _lib.act_dtype(x)
     lib = _lib.load()
     if ref is not None:
         if ref.shape != x.shape:
             raise RuntimeError("fused_bias_act: ref shape mismatch")
+        if ref.dtype != x.dtype:          # (double-backward corner: f32 cotangent, bf16 saved activation)
+            ref = ref.to(x.dtype)
         # the incoming gradient follows the layout of the saved activation
         if ref.dim() == 4 and ref.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         else:
             ref, x = ref.contiguous(), x.contiguous()
     x, layout, c, inner = _layout_of(x)
+    if dt == _lib.BF16 and layout == _lib.NCHW and inner != 1:     # bf16 kernels are NHWC-only
+        if x.dim() == 4:
+            x = x.contiguous(memory_format=torch.channels_last)
+            ref = None if ref is None else ref.contiguous(memory_format=torch.channels_last)
+            layout = _lib.NHWC
+        else:
+            y32 = bias_act_raw(x.float(), bias, None if ref is None else ref.float(), grad, alpha, scale, want_bias_grad, act)
+            return (y32[0].to(x.dtype), y32[1]) if want_bias_grad else y32.to(x.dtype)
     if bias is not None:
         if bias.numel() != c:
             raise RuntimeError(f"fused_bias_act: bias has {bias.numel()} elements, expected {c}")
@@ -63,7 +72,7 @@ def bias_act_raw(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[to
     bg = torch.zeros(c, device=x.device, dtype=torch.float32) if want_bias_grad else None
     if x.numel():
         rc = lib.ideas_fused_bias_act(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bias), _lib.ptr(ref), _lib.ptr(bg),
-                                      x.numel(), c, inner, layout, act, grad, float(alpha), float(scale), _lib.F32,
+                                      x.numel(), c, inner, layout, act, grad, float(alpha), float(scale), dt,
                                       _lib.stream_ptr())
         _lib.check(rc, "ideas_fused_bias_act")
     return (y, bg) if want_bias_grad else y

@@ -22,6 +22,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib
+from ..precision import to_act, to_f32
 from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, weight_grad, _nhwc
 from .conv_plan import ConvGeom, convT_out_size
 from .upfirdn2d import upfirdn2d
@@ -33,7 +34,11 @@ def pixel_dot(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     a, g = _nhwc(a), _nhwc(g)
     b, c, h, w = a.shape
     out = torch.zeros((b, c), device=a.device, dtype=torch.float32)
-    rc = _lib.load().ideas_pixel_dot(_lib.ptr(out), _lib.ptr(a), _lib.ptr(g), b, h * w, c, _lib.F32, _lib.stream_ptr())
+    if a.dtype != g.dtype:
+        a, g = a.float(), g.float()
+    if a.dtype == torch.bfloat16 and c % 4:
+        a, g = a.float(), g.float()
+    rc = _lib.load().ideas_pixel_dot(_lib.ptr(out), _lib.ptr(a), _lib.ptr(g), b, h * w, c, _lib.act_dtype(a), _lib.stream_ptr())
     _lib.check(rc, "ideas_pixel_dot")
     return out
 
@@ -120,12 +125,14 @@ class _ModConv(Function):
 def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: float, act_gain: float):
     """(g_pre, bias_grad[C], dot[B,C]) from the incoming gradient and the saved post-activation output."""
     gy, out = _nhwc(gy), _nhwc(out)
+    if gy.dtype != out.dtype:
+        gy = gy.to(out.dtype)
     b, c, h, w = out.shape
     gpre = torch.empty_like(out)
     bg = torch.zeros(c, device=out.device, dtype=torch.float32)
     dot = torch.zeros((b, c), device=out.device, dtype=torch.float32)
     rc = _lib.load().ideas_act_bwd_dot(_lib.ptr(gpre), _lib.ptr(bg), _lib.ptr(dot), _lib.ptr(gy), _lib.ptr(out),
-                                       _lib.ptr(bias), b, h * w, c, float(alpha), float(act_gain), _lib.F32,
+                                       _lib.ptr(bias), None, b, h * w, c, float(alpha), float(act_gain), _lib.act_dtype(out),
                                        _lib.stream_ptr())
     _lib.check(rc, "ideas_act_bwd_dot")
     return gpre, bg, dot
@@ -216,6 +223,9 @@ def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
     here) used after the stride-2 transposed conv (stylegan2/model.py:202-208, 258-261); it already carries the x4
     upsample gain.  ``act_bias`` fuses the FusedLeakyReLU that always follows (stylegan2/model.py:374-375)."""
     _lib.require_cuda(x, weight, style)
+    x, style = to_act(x), to_f32(style)
+    if resid is not None:
+        resid = to_act(resid)
     w = weight[0] if weight.dim() == 5 else weight
     cout, cin, k, _ = w.shape
     if _SECOND_ORDER[0] and torch.is_grad_enabled() and resid is None:

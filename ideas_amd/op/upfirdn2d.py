@@ -20,8 +20,7 @@ def upfirdn2d_raw(x: torch.Tensor, fir: torch.Tensor, up: Tuple[int, int], down:
                   pad: Tuple[int, int, int, int], out_hw: Tuple[int, int], flip: bool, gain: float = 1.0) -> torch.Tensor:
     """One launch.  ``pad = (x0, x1, y0, y1)``; ``flip=True`` is the op's own (correlate-with-flipped-FIR) semantics."""
     _lib.require_cuda(x, fir)
-    if x.dtype != torch.float32:
-        raise RuntimeError(f"upfirdn2d: only float32 is implemented, got {x.dtype}")
+    dt = _lib.act_dtype(x)
     if x.dim() != 4:
         raise RuntimeError("upfirdn2d expects a 4-D [B, C, H, W] tensor")
     lib = _lib.load()
@@ -32,7 +31,7 @@ def upfirdn2d_raw(x: torch.Tensor, fir: torch.Tensor, up: Tuple[int, int], down:
         raise RuntimeError(f"upfirdn2d: empty output {oh}x{ow}")
     if x.is_contiguous(memory_format=torch.channels_last):
         layout, fmt = _lib.NHWC, torch.channels_last
-    elif x.is_contiguous():
+    elif x.is_contiguous() and dt == _lib.F32:
         layout, fmt = _lib.NCHW, torch.contiguous_format
     else:
         x = x.contiguous(memory_format=torch.channels_last)
@@ -40,7 +39,7 @@ def upfirdn2d_raw(x: torch.Tensor, fir: torch.Tensor, up: Tuple[int, int], down:
     fir = fir.contiguous().to(torch.float32)
     y = torch.empty((b, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=fmt)
     rc = lib.ideas_upfirdn2d(_lib.ptr(y), _lib.ptr(x), _lib.ptr(fir), b, c, h, w, oh, ow, kh, kw, up[0], up[1],
-                             down[0], down[1], pad[0], pad[2], float(gain), int(flip), layout, _lib.F32,
+                             down[0], down[1], pad[0], pad[2], float(gain), int(flip), layout, dt,
                              _lib.stream_ptr())
     _lib.check(rc, "ideas_upfirdn2d")
     return y

@@ -35,8 +35,12 @@ enum { IDEAS_NCHW = 0, IDEAS_NHWC = 1 };
  *   IDEAS_F32     contraction on the f32 matrix instruction (v_mfma_f32_32x32x2_f32): an exact fmaf chain.
  *   IDEAS_F32_B3  operands split exactly into three bf16 planes, six plane-pair products on the bf16 matrix
  *                 instruction with f32 accumulation (csrc/conv_b3.hip): the same f32 error class at 2.67x the matrix
- *                 rate.  Shapes the split kernels do not cover (Cin % 16 != 0) run the IDEAS_F32 kernel. */
-enum { IDEAS_F32 = 0, IDEAS_F32_B3 = 1 };
+ *                 rate.  Shapes the split kernels do not cover (Cin % 16 != 0) run the IDEAS_F32 kernel.
+ *   IDEAS_BF16    bf16 mixed precision (BASELINE.json configs[4]; the reference's ops dispatch half as well,
+ *                 fused_bias_act_kernel.cu:78, upfirdn2d_kernel.cu:311): activations (x, y, gy, resid) are bf16 in HBM,
+ *                 contraction on v_mfma_f32_32x32x16_bf16 with f32 accumulation and an f32 epilogue; weights stay f32 masters
+ *                 (the MFMA kernels read a bf16 pack of them, ideas_bf16_pack_weights), scales / biases / weight gradients f32. */
+enum { IDEAS_F32 = 0, IDEAS_F32_B3 = 1, IDEAS_BF16 = 2 };
 
 enum {
     IDEAS_OK = 0,
@@ -139,6 +143,23 @@ int ideas_b3_wino_supported(const ideas_conv_params* p);
 int ideas_b3_wino_split_weights(void* planes, const void* w, int N, int C, int64_t sn, int64_t sky, int64_t skx, int64_t sc,
                                 int64_t base, void* stream);
 
+/* bf16 mixed precision (dtype IDEAS_BF16 of ideas_conv_igemm / ideas_conv_wgrad; csrc/conv_bf16.hip).
+ *   ideas_bf16_conv_supported   1 if ideas_conv_igemm(..., IDEAS_BF16, ...) covers the geometry: Cin % 32 == 0, Cout % 4 == 0,
+ *                               <= 32 taps, tensors < 4 GiB (`scaled`: an in_scale will be passed; M tiles are then cut per sample
+ *                               and the block scales its weight tile by in_scale[b, :]).
+ *   ideas_bf16_wgrad_supported  the same for ideas_conv_wgrad: Cin % 8 == 0, Cout % 8 == 0, OW a divisor or a multiple of 32.
+ *   ideas_bf16_pack_weights     wmat f32 [Cout][K] (K = taps*Cin, the matrix ideas_conv_igemm takes for IDEAS_F32) -> `pack`,
+ *                               Cout*K bf16 laid out [K/32][Cout][32], K-steps ordered (ci/32, ty, tx), 16-byte chunk c of row
+ *                               n stored at position c ^ ((n >> 2) & 3) (the LDS swizzle, so the kernel's DMA is linear).
+ *                               With IDEAS_BF16 the `wmat` argument of ideas_conv_igemm is this buffer. */
+int ideas_bf16_conv_supported(const ideas_conv_params* p, int scaled);
+int ideas_bf16_wgrad_supported(const ideas_conv_params* p, int scaled);
+int ideas_bf16_pack_weights(void* pack, const void* wmat, int Cout, int K, int Cin, void* stream);
+/* 1 if ideas_conv_direct / ideas_conv_wgrad_direct with IDEAS_BF16 are the intended path for the geometry: the HBM-bound
+ * pointwise layers with <= 8 input or output channels (from-RGB, to-RGB and their gradients).  Everything else without a bf16
+ * MFMA kernel (a handful of tiny layers) is computed by the caller in f32 on casts. */
+int ideas_bf16_direct_supported(const ideas_conv_params* p);
+
 /* Weight gradient of the same family:  for every o, tap, ci
  *     gw[o][(ty*TX+tx)*Cin + ci] (+)= sum over (b,oy,ox) of  G(b,oy,ox,o) * X(b, iy, ix, ci)
  * with G = gy[b, oy*osy+ooy, ox*osx+oox, o] * (out_scale ? out_scale[b*Cout+o] : 1),
@@ -166,6 +187,7 @@ int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x, const flo
 
 /* Generic direct convolution (VALU) with the same parameterisation and epilogue; any Cin/Cout. Used for the
  * handful of tiny-K layers (RGB / N-channel inputs) where the MFMA tile would be empty. */
+/* (dtype IDEAS_F32, or IDEAS_BF16: bf16 x / y / resid / gy with f32 weights, scales, bias and weight gradient) */
 int ideas_conv_direct(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,
                       const float* bias, const void* resid, const ideas_conv_params* p, int dtype, void* stream);
 int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
@@ -186,9 +208,11 @@ int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, 
  *     gpre      = (out > 0 ? gy : gy*alpha) * act_gain
  *     bias_grad[c] += sum_{b,p} gpre                       (ZEROED float[C])
  *     dot[b,c]     += sum_p gpre * (inverse_act(out) - bias[c])   (ZEROED float[B*C]; = <gpre, demodulated conv output>)
- * so neither the pre-activation tensor nor a separate bias-gradient / pixel-dot pass is needed. */
+ * so neither the pre-activation tensor nor a separate bias-gradient / pixel-dot pass is needed.
+ * gpre_scale (optional float[B*C]): the STORED gpre is multiplied by it (bias_grad and dot are not) -- the bf16 path passes
+ * the demodulation factor here, so its input- and weight-gradient kernels take the already-scaled gradient. */
 int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out, const float* bias,
-                      int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
+                      const float* gpre_scale, int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
 
 /* Adjoint of ReflectionPad2d(pad) in NHWC: gx [B,H,W,C] = fold of gpadded [B,H+2pad,W+2pad,C] (mirrored border rows /
  * columns added back onto their sources).  Any C (16-byte vectors when C % 4 == 0).  Used by the input gradient of the reflect-padded 3x3 convs of
