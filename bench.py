@@ -46,8 +46,11 @@ def flop_per_image(elided: bool, d_reg_every: int = 16, shared: bool = True) -> 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=16)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=48, help="timed iterations (48 = three lazy-R1 iterations at d_reg_every 16)")
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                   help="activation dtype: f32 = the reference's arithmetic class (headline); bf16 = BASELINE.json configs[4] "
+                        "mixed precision (bf16 activations + bf16 MFMA, f32 accumulation, f32 master weights)")
     p.add_argument("--batch", type=int, default=32, help="images per GPU")
     p.add_argument("--image-size", type=int, default=256)
     p.add_argument("--N", type=int, default=1)
@@ -60,6 +63,44 @@ def parse():
     p.add_argument("--roofline", choices=["on", "off", "only"], default="on")
     p.add_argument("--roofline-launches", type=int, default=20)
     return p.parse_args()
+
+
+def roofline_probe_bf16(device, batch: int, launches: int):
+    """bf16 mode: the dominant kernel is conv_bf16_kernel<2,2,2,2,true,false> (csrc/conv_bf16.hip) on the same heaviest instance,
+    G.layers.7.conv2.  One bf16 MFMA product per algorithmic product: `peak` is the dense bf16 MFMA peak itself."""
+    from ideas_amd.op import conv as CV, conv_plan
+    from ideas_amd.op.conv_plan import ConvGeom
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(batch, 128, 256, 256, generator=g).to(device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(128, 128, 3, 3, generator=g).to(device).contiguous(memory_format=torch.channels_last))
+    s = (torch.randn(batch, 128, generator=g) * 0.5 + 1).to(device)
+    d = (torch.rand(batch, 128, generator=g) + 0.5).to(device)
+    geom = ConvGeom(3, 3, 1, 1, False)
+    conv_plan.cache_begin()              # as inside train_iteration: the bf16 weight pack is made once per optimiser step
+    try:
+        for _ in range(3):
+            CV.conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            CV.conv_fwd_raw(x, w, geom, 0.03, lin=s, lout=d)
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        conv_plan.cache_end()
+    ms = e0.elapsed_time(e1) / launches
+    flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    alg_bytes = 2.0 * batch * 256 * 256 * 128 * 2          # read x + write y, bf16
+    traffic, note = _pmc_traffic("conv_bf16_kernel", "r02_pmc_bf16") if batch == 32 else (None, None)
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": note,
+            "kernel": "conv_bf16_kernel<2,2,2,2,true,false> (LDS-DMA implicit GEMM, v_mfma_f32_32x32x16_bf16, one product per MFMA, "
+                      "f32 accumulate, per-block weight modulation) on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch,
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_hbm_gbs": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
+            "hbm_frac_of_8tbs": round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 
 
 def roofline_probe(device, batch: int, launches: int):
@@ -97,7 +138,7 @@ def roofline_probe(device, batch: int, launches: int):
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         b3w = CV.B3_WINO
         kname = "conv_b3_wino_kernel" if b3w else "conv_b3_kernel"
-        traffic, traffic_note = _pmc_traffic(kname, "r01_pmc_b3w" if b3w else "r01_pmc_b3") if batch == 32 else (None, None)
+        traffic, traffic_note = _pmc_traffic(kname, "r02_pmc_b3w" if b3w else "r02_pmc_b3") if batch == 32 else (None, None)
         executed = achieved * (4.0 if b3w else 6.0)       # bf16 MFMA FLOPs issued per algorithmic f32 FLOP
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -111,7 +152,7 @@ def roofline_probe(device, batch: int, launches: int):
                 "executed_bf16_tflops": round(executed, 1), "mfma_executed_frac": round(executed / PEAK_BF16_MFMA_TFLOPS, 4),
                 "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
     wino = CV.WINOGRAD
-    traffic, traffic_note = _pmc_traffic("wino", "r01a_f32_pmc") if (wino and batch == 32) else (None, None)
+    traffic, traffic_note = _pmc_traffic("wino", "r02_pmc_f32") if (wino and batch == 32) else (None, None)
     kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino
               else "conv_igemm_kernel<2,2,2,2,true,false,true> (direct implicit GEMM)")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -120,11 +161,27 @@ def roofline_probe(device, batch: int, launches: int):
             "mfma_executed_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
+def _src_sha(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "ideas_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(kernel_substr: str, prefix: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<prefix>_*.csv;
     the counters cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 reports half the bytes of a wide
-    coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB."""
+    coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB.  The passes carry a sidecar
+    profiles/<prefix>_source.json = {"files": [...], "sha": ...} written by tools/collect_profiles.sh with the hash of the
+    kernel sources they measured; if the sources changed since (or there is no sidecar) the figure is stale -> null."""
     import csv
+    try:
+        side = json.load(open(os.path.join(ROOT, "profiles", prefix + "_source.json")))
+        if _src_sha(side["files"]) != side["sha"]:
+            return None, "profiles/%s_* are older than csrc/%s: stale, not reported" % (prefix, ",".join(side["files"]))
+    except Exception:
+        return None, "no PMC pass of the current kernel sources under profiles/ (%s_source.json)" % prefix
     try:
         vals = {}
         for name, fn in (("FETCH_SIZE", prefix + "_fetch_size.csv"), ("WRITE_SIZE", prefix + "_write_size.csv")):
@@ -226,9 +283,13 @@ def main():
     from ideas_amd.ddp import GradReducer
     _lib.load()
 
+    bf16 = a.precision == "bf16"
+    probe = roofline_probe_bf16 if bf16 else roofline_probe
     if a.roofline == "only":
-        print(json.dumps({"roofline": roofline_probe(device, a.batch, a.roofline_launches)}))
+        print(json.dumps({"roofline": probe(device, a.batch, a.roofline_launches)}))
         return
+    from ideas_amd import precision
+    precision.set_activation_dtype(a.precision)
 
     args = TS.default_args(image_size=a.image_size, batch_size=a.batch, N=a.N,
                            elide_second_backward=not a.literal_second_backward, num_iters=10 ** 9,
@@ -275,7 +336,9 @@ def main():
     n_r1 = sum(1 for i in range(1, a.steps + 1) if i % args.d_reg_every == 0)
     from ideas_amd import _lib
     from ideas_amd.op import conv as _CV
-    conv_math = ("f32 tensors; MFMA convs contract an exact 3-way bf16 split of both operands (6 bf16 MFMA products per "
+    conv_math = ("bf16 activations in HBM, bf16 MFMA (one product per MFMA) with f32 accumulation and f32 epilogues; f32 master "
+                 "weights, gradients and optimiser state (ideas_amd/precision.py, csrc/conv_bf16.hip)") if bf16 else \
+                ("f32 tensors; MFMA convs contract an exact 3-way bf16 split of both operands (6 bf16 MFMA products per "
                  "f32 product, f32 accumulate; f32 error class, tests/test_ops_gpu.py)" if _CV.MATH == _lib.F32_B3
                  else "f32 MFMA (v_mfma_f32_32x32x2_f32)" + (" + 1-D Winograd F(2,3)" if _CV.WINOGRAD else ""))
     ips = world * a.batch * a.steps / dt
@@ -283,9 +346,9 @@ def main():
     out = {
         "metric": "train images/sec at 256x256 (G+D+Ex step)", "value": round(ips, 3), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
-                               "full-width nets, HIP kernels (BASELINE.json configs[2])" % (a.N, a.image_size, a.image_size, a.batch),
+                               "full-width nets, HIP kernels (BASELINE.json configs[%d])" % (a.N, a.image_size, a.image_size, a.batch, 4 if bf16 else 2),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
                    "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
                    "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off",
@@ -298,7 +361,7 @@ def main():
     if a.roofline == "on":
         del trainer
         torch.cuda.empty_cache()
-        out["roofline"] = roofline_probe(device, a.batch, a.roofline_launches)
+        out["roofline"] = probe(device, a.batch, a.roofline_launches)
     if a.cpu_baseline == "auto" and world == 1:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

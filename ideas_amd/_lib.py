@@ -61,7 +61,7 @@ _PROTOS = {
     "ideas_bf16_conv_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int]),
     "ideas_bf16_wgrad_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int]),
     "ideas_bf16_direct_supported": (C.c_int, [C.POINTER(ConvParams)]),
-    "ideas_bf16_pack_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_bf16_pack_weights": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_conv3x3_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv3x3_wino_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv_direct": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),

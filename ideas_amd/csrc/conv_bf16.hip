@@ -11,9 +11,11 @@
 //       offset; a padding tap gets offset 0xffffffff, for which the DMA writes zeros (probed: tools/probes/dma.hip);
 //     * weights are packed once per optimiser step (ideas_bf16_pack_weights) into [K/32][Cout][32] bf16 with that swizzle
 //       already applied, so a B tile is one contiguous block that the DMA copies linearly;
-//     * modulated convs (per-sample input scale s[b, ci]): M tiles are cut per image (a tile never straddles two samples; the
-//       last tile of an image is partial), so the block scales its WEIGHT tile by s[b, :] on the way into LDS — the reference's per-sample weights (stylegan2/model.py:240-248)
-//       materialised per block in LDS instead of per sample in HBM; the activation path stays pure DMA;
+//     * modulated convs (per-sample input scale s[b, ci]): the pack kernel writes one bf16 pack per sample, w * s[b, :] -- the
+//       reference's per-sample weights (stylegan2/model.py:240-248), but bf16, swizzled and alive for one launch only (at most
+//       151 MB for a 512x512x3x3 layer at B = 32, 0.06 ms of HBM time next to a 0.9 ms convolution); M tiles are cut per image
+//       (the last tile of an image is partial) and a block DMAs the B tiles of ITS image, so both operand paths stay pure DMA;
+//     * three LDS stages and one raw s_barrier per K-step with a COUNTED s_waitcnt vmcnt: a DMA has two K-steps to land;
 //     * the MFMA runs with the weights as its A operand: a lane then owns ONE pixel and four consecutive output channels per
 //       accumulator quad, i.e. the epilogue packs 4 bf16 and issues 8-byte stores (4x fewer store instructions than a
 //       channel-per-lane layout with 2-byte stores).
@@ -56,42 +58,63 @@ __device__ __forceinline__ uint4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff,
 
 // ---------------------------------------------------------------------------------------------------------------
 // weights: f32 [Cout][K] (K = (ty, tx, ci) contiguous) -> bf16 [K/32][Cout][32], K-step = (ci/32, ty, tx), 16-byte chunk c of
-// row n stored at position c ^ ((n >> 2) & 3)
+// row n stored at position c ^ ((n >> 2) & 3).  With `scale` (float [B][Cin]): B packs, pack b holds w[n][k] * scale[b][ci(k)]
+// -- the reference's per-sample modulated weights (stylegan2/model.py:240-248), as bf16 and only for the life of one launch.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_weights_kernel(uint4* __restrict__ dst, const float4* __restrict__ w, int Cout, int K,
-                                                           int Cin) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(uint4* __restrict__ dst, const float4* __restrict__ w,
+                                                           const float* __restrict__ scale, int Cout, int K, int Cin) {
     const int64_t n8 = (int64_t)Cout * (K / 8);
     const int ntaps = K / Cin;
+    const int b = blockIdx.y;
+    const float* sb = scale ? scale + (int64_t)b * Cin : nullptr;
+    uint4* out = dst + (int64_t)b * n8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i % (K / 8)) * 8;
         const int n = (int)(i / (K / 8));
         const int tap = k / Cin, ci = k - tap * Cin;
         const int step = (ci >> 5) * ntaps + tap;
         const int c = (ci & 31) >> 3;
-        const float4 a = w[2 * i], b = w[2 * i + 1];
-        const uint4 v = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
-        dst[((int64_t)step * Cout + n) * 4 + (c ^ ((n >> 2) & 3))] = v;
+        float4 u = w[2 * i], v = w[2 * i + 1];
+        if (sb) {
+            const float4 s0 = *reinterpret_cast<const float4*>(sb + ci), s1 = *reinterpret_cast<const float4*>(sb + ci + 4);
+            u = make_float4(u.x * s0.x, u.y * s0.y, u.z * s0.z, u.w * s0.w);
+            v = make_float4(v.x * s1.x, v.y * s1.y, v.z * s1.z, v.w * s1.w);
+        }
+        out[((int64_t)step * Cout + n) * 4 + (c ^ ((n >> 2) & 3))] =
+            make_uint4(pk_bf16(u.x, u.y), pk_bf16(u.z, u.w), pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward family
 // ---------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
+// Pipeline: NST LDS stages, ONE raw barrier per K-step.  Step t:  wait until this wave's DMA pieces of tile t have landed
+// (counted vmcnt: the pieces of tiles t+1 .. t+NST-2 stay in flight), barrier (=> every wave's pieces of tile t are in LDS
+// and every wave is done reading tile t-1), issue the DMA of tile t+NST-1 into the stage tile t-1 occupied, then fragments +
+// MFMAs of tile t.  A DMA has NST-1 steps to land instead of one.  Every wave issues exactly DMA_PER pieces per tile, so the
+// count is a compile-time constant.
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int MT, int NT, bool PERIMG, bool REFLECT>
 __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
-                                                           const void* __restrict__ wpack, const float* __restrict__ in_scale,
-                                                           const float* __restrict__ out_scale, const float* __restrict__ bias,
-                                                           const bf16_t* __restrict__ resid, ideas_conv_params p, int tiles_n,
-                                                           int tiles_per_img, unsigned x_bytes, unsigned w_bytes) {
+                                                           const void* __restrict__ wpack, const float* __restrict__ out_scale,
+                                                           const float* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                           ideas_conv_params p, int tiles_n, int tiles_per_img, unsigned x_bytes,
+                                                           unsigned w_bytes) {
     static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int NST = 3;
     constexpr int BM = WM * MT * 32;      // pixels of the tile
     constexpr int BN = WN * NT * 32;      // output channels of the tile
     static_assert(BM % 64 == 0, "each wave issues whole 16-row DMA pieces");
     constexpr int A_PER = BM / 64;        // 16-row DMA pieces of the A tile per wave
-    constexpr int B_PIECES = BN / 16;     // 16-row pieces of the B tile (spread over the waves)
+    constexpr int B_PIECES = BN / 16;     // 16-row pieces of the B tile
     constexpr int B_PER = (B_PIECES + 3) / 4;
+    constexpr int DMA_PER = A_PER + B_PER;
     constexpr int BUF = (BM + BN) * ROW;
-    constexpr int SMEM = 2 * BUF > BM * 12 ? 2 * BUF : BM * 12;
+    constexpr int SMEM = NST * BUF > BM * 12 ? NST * BUF : BM * 12;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -99,15 +122,19 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
     const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
     const int n0 = tile_n * BN;
-    // row r of the tile -> output point.  Plain: consecutive points of the flattened (b, oy, ox) grid.  SCALE: tiles are cut
-    // per image (tile_m = img * tiles_per_img + j), rows past the image's last point are clamped and not stored.
+    // row r of the tile -> output point.  Plain: consecutive points of the flattened (b, oy, ox) grid.  PERIMG (per-sample
+    // weights): tiles are cut per image (tile_m = img * tiles_per_img + j), rows past the image's last point are clamped and
+    // not stored, and the weight pack of image `img` is used.
     const int OHW = p.OH * p.OW;
-    const int img = SCALE ? tile_m / tiles_per_img : 0;
-    const int64_t m0 = SCALE ? (int64_t)img * OHW + (int64_t)(tile_m - img * tiles_per_img) * BM : (int64_t)tile_m * BM;
-    const int64_t mend = SCALE ? (int64_t)(img + 1) * OHW : M;     // first point this tile must not touch
+    const int img = PERIMG ? tile_m / tiles_per_img : 0;
+    const int64_t m0 = PERIMG ? (int64_t)img * OHW + (int64_t)(tile_m - img * tiles_per_img) * BM : (int64_t)tile_m * BM;
+    const int64_t mend = PERIMG ? (int64_t)(img + 1) * OHW : M;     // first point this tile must not touch
+    const int K = p.TY * p.TX * p.Cin;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (int)w_bytes, (int)RSRC);
+    const unsigned w_img = PERIMG ? (unsigned)img * (unsigned)K * (unsigned)p.Cout * 2u : 0u;   // this image's pack
+    const unsigned w_end = w_img + (unsigned)K * (unsigned)p.Cout * 2u;
 
     // ---- A: this lane's DMA slots.  Piece q (16 rows) is issued by wave q & 3; lane l fills LDS slot l of the piece:
     // row = 16 q + (l >> 2), position l & 3, which must hold chunk c = (l & 3) ^ ((row >> 2) & 3) of that row.
@@ -137,22 +164,13 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
         }
         a_inv[j] = inv;
     }
-    // ---- B
-    // plain: linear DMA of 16-row pieces (the pack is pre-swizzled); SCALE: thread t owns (row t >> 2 [+ 64 j], position t & 3)
-    constexpr int BS_PER = (BN * 4 + 255) / 256;
-    const float* srow = SCALE ? in_scale + (int64_t)img * p.Cin : nullptr;
 
     int k_ci = 0, k_tx = 0, k_ty = 0, k_tap = 0;   // block-uniform walk over K = (ci/32, ty, tx)
-    auto advance = [&]() {
-        const int nx = k_tx + 1, gx = 1 - (int)((unsigned)(nx - p.TX) >> 31);
-        k_tx = nx - gx * p.TX;
-        const int ny = k_ty + gx, gy = 1 - (int)((unsigned)(ny - p.TY) >> 31);
-        k_ty = ny - gy * p.TY;
-        k_tap = (k_tap + 1) * (1 - gy);
-        k_ci += gy * KB;
-    };
-    auto dmaA = [&](int buf) {                      // uses (k_ty, k_tx, k_ci, k_tap) of the tile being fetched
-        unsigned char* base = smem + buf * BUF;
+    int k_next = 0;                                // index of the next tile to fetch
+    // Fetch the next tile (k_next) into stage `st`.  Tiles past K: the activation pieces are fetched from wherever the walk
+    // points (in range or zero-filled), the weight pieces get an out-of-range offset (zeros) -- never multiplied.
+    auto fetch = [&](int st) {
+        unsigned char* base = smem + st * BUF;
         const unsigned tapoff = (unsigned)(((k_ty * p.dy) * p.IW + k_tx * p.dx) * p.Cin + k_ci) * 2u;
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
@@ -165,47 +183,22 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + (wave + 4 * j) * 1024), 16, (int)off, 0, 0, 0);
         }
-    };
-    auto dmaB = [&](int buf, int kt) {
-        unsigned char* base = smem + buf * BUF + BM * ROW;
         // (the K-step offset is folded into the per-lane offset: only that one is range-checked by a raw buffer)
-        const unsigned soff = (unsigned)kt * (unsigned)p.Cout * 64u;
+        const unsigned soff = w_img + (unsigned)k_next * (unsigned)p.Cout * 64u;
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const int q = wave + 4 * j;
-            if (q < B_PIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(base + q * 1024), 16,
-                                                         (int)((unsigned)((n0 + q * 16) * 64 + lane * 16) + soff), 0, 0, 0);
+            const int q = (wave + 4 * j) % B_PIECES;        // narrow tiles: some waves repeat a piece (same bytes, same place)
+            unsigned off = soff + (unsigned)((n0 + q * 16) * 64 + lane * 16);
+            off = off < w_end ? off : 0xffffffffu;          // past this image's pack (last tiles, rows >= Cout of the last step)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(base + BM * ROW + q * 1024), 16, (int)off, 0, 0, 0);
         }
-    };
-    // SCALE: register path for B (one stage): load at the top of a step, scale + store after the MFMAs
-    uint4 rb[BS_PER];
-    float4 rs0[BS_PER], rs1[BS_PER];
-    auto gloadBS = [&](int kt, int ci0) {
-        const unsigned soff = (unsigned)kt * (unsigned)p.Cout * 64u;
-#pragma unroll
-        for (int j = 0; j < BS_PER; ++j) {
-            const int r = ((t >> 2) + 64 * j) % BN;
-            const int c = (t & 3) ^ ((r >> 2) & 3);
-            rb[j] = bload4(rw, (unsigned)((n0 + r) * 64 + (t & 3) * 16) + soff, 0);
-            const int ci = ci0 + c * 8;
-            const bool ok = ci < p.Cin;             // tiles past K: any finite scale will do
-            rs0[j] = ok ? *reinterpret_cast<const float4*>(srow + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rs1[j] = ok ? *reinterpret_cast<const float4*>(srow + ci + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstoreBS = [&](int buf) {
-        unsigned char* base = smem + buf * BUF + BM * ROW;
-#pragma unroll
-        for (int j = 0; j < BS_PER; ++j) {
-            const int r = ((t >> 2) + 64 * j) % BN;
-            uint4 v = rb[j];
-            v.x = pk_bf16(bf_lo(v.x) * rs0[j].x, bf_hi(v.x) * rs0[j].y);
-            v.y = pk_bf16(bf_lo(v.y) * rs0[j].z, bf_hi(v.y) * rs0[j].w);
-            v.z = pk_bf16(bf_lo(v.z) * rs1[j].x, bf_hi(v.z) * rs1[j].y);
-            v.w = pk_bf16(bf_lo(v.w) * rs1[j].z, bf_hi(v.w) * rs1[j].w);
-            *reinterpret_cast<uint4*>(base + r * ROW + (t & 3) * 16) = v;
-        }
+        ++k_next;
+        const int nx = k_tx + 1, gx = 1 - (int)((unsigned)(nx - p.TX) >> 31);
+        k_tx = nx - gx * p.TX;
+        const int ny = k_ty + gx, gy = 1 - (int)((unsigned)(ny - p.TY) >> 31);
+        k_ty = ny - gy * p.TY;
+        k_tap = (k_tap + 1) * (1 - gy);
+        k_ci += gy * KB;
     };
 
     const int wm = wave / WN, wn = wave % WN;
@@ -224,21 +217,15 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
     const int b_off = BM * ROW + ((wn * NT) * 32 + li) * ROW;
     const int pos0 = ((0 + lh) ^ rsw) * 16, pos1 = ((2 + lh) ^ rsw) * 16;
 
-    const int K = p.TY * p.TX * p.Cin;
     const int nk = K / KB;
-    // prologue: tile 0 -> buffer 0
-    if (SCALE) { gloadBS(0, 0); } else dmaB(0, 0);
-    dmaA(0);
-    advance();
-    if (SCALE) lstoreBS(0);
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) fetch(st);               // prologue: tiles 0 .. NST-2
+    int st_cur = 0, st_free = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        // fetch tile kt+1 (past K: padding-mask / out-of-range zeros or finite garbage that is never multiplied)
-        if (SCALE) gloadBS(kt + 1, k_ci); else dmaB(buf ^ 1, kt + 1);
-        dmaA(buf ^ 1);
-        advance();
-        const unsigned char* base = smem + buf * BUF;
+        wait_vmcnt<(NST - 2) * DMA_PER>();          // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();               // ... and everybody else's; all waves are done with tile kt-1
+        fetch(st_free);                             // tile kt+NST-1 into the stage tile kt-1 occupied
+        const unsigned char* base = smem + st_cur * BUF;
         bf16x8 fx[MT][2], fw[NT][2];
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
@@ -257,9 +244,11 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
 #pragma unroll
                 for (int b = 0; b < NT; ++b)   // weights as the A operand: rows of D = output channels, columns = pixels
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][s], fx[a][s], acc[a][b], 0, 0, 0);
-        if (SCALE) lstoreBS(buf ^ 1);
-        __syncthreads();                            // DMA of tile kt+1 landed (vmcnt(0) rides on the barrier); buffer `buf` is free
+        st_free = st_cur;
+        st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
     }
+    wait_vmcnt<0>();                                // drain the tiles fetched past K before the stages are reused
+    __syncthreads();
 
     // ---- epilogue: lane = pixel li of block a; registers 4g..4g+3 = channels 8g + 4lh .. +3 of block b --------------------
     int64_t* row_off = reinterpret_cast<int64_t*>(smem);
@@ -317,24 +306,24 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
 }
 
 template <int WM, int WN, int MT, int NT>
-int launch_bf16_cfg(void* y, const void* x, const void* wpack, const float* in_scale, const float* out_scale, const float* bias,
+int launch_bf16_cfg(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                     const void* resid, const ideas_conv_params* p, hipStream_t stream) {
     constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
     const int64_t M = (int64_t)p->B * p->OH * p->OW;
     const int tpi = (int)ideas_cdiv((int64_t)p->OH * p->OW, BM_);
-    const int64_t tm = in_scale ? (int64_t)p->B * tpi : ideas_cdiv(M, BM_);
+    const int64_t tm = per_image ? (int64_t)p->B * tpi : ideas_cdiv(M, BM_);
     const int tn = (int)ideas_cdiv(p->Cout, BN_);
     if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
-    const unsigned w_bytes = (unsigned)((int64_t)p->TY * p->TX * p->Cin * p->Cout * 2);
-    auto go = [&](auto sc, auto rf) {
-        hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
-                           dim3(256), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack, in_scale, out_scale, bias,
-                           (const bf16_t*)resid, *p, tn, tpi, x_bytes, w_bytes);
+    const unsigned w_bytes = (unsigned)((int64_t)(per_image ? p->B : 1) * p->TY * p->TX * p->Cin * p->Cout * 2);
+    auto go = [&](auto pi, auto rf) {
+        hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, decltype(pi)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
+                           dim3(256), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack, out_scale, bias, (const bf16_t*)resid, *p, tn,
+                           tpi, x_bytes, w_bytes);
     };
     using T = std::true_type;
     using F = std::false_type;
-    if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    if (per_image) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
     else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
     return ideas_launch_status();
 }
@@ -362,10 +351,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
     constexpr int BM = WM * MT * 32;   // output channels of the tile
     constexpr int BN = WN * NT * 32;   // k columns of the tile
     constexpr int PIECES_G = 32 * BM * 2 / 1024, PIECES_X = 32 * BN * 2 / 1024;    // 1 KiB DMA pieces per K-step
-    constexpr int PIECES = PIECES_G + PIECES_X;
-    constexpr int PER = (PIECES + 3) / 4;
+    // every wave issues PER_G pieces of G then PER_X pieces of X per step (narrow tiles: some pieces twice) -- which operand a
+    // slot belongs to is a compile-time property of the slot, so the buffer descriptor of each DMA is known to be uniform
+    constexpr int PER_G = (PIECES_G + 3) / 4, PER_X = (PIECES_X + 3) / 4;
+    constexpr int PER = PER_G + PER_X;
+    constexpr int NST = 3;                  // LDS stages (see conv_bf16_kernel: counted vmcnt, one raw barrier per step)
     constexpr int BUF = 32 * (BM + BN) * 2;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * BUF];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int Ktot = p.TY * p.TX * p.Cin;
@@ -391,10 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
     int w_b[PER], w_oy[PER], w_ox[PER], w_p[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int q = wave + 4 * j;
-        const bool is_g = q < PIECES_G;
-        const int slot = (is_g ? q : q - PIECES_G) * 64 + lane;
-        s_valid[j] = q < PIECES;
+        const bool is_g = j < PER_G;
+        const int q = is_g ? (wave + 4 * j) % PIECES_G : (wave + 4 * (j - PER_G)) % PIECES_X;    // piece within its operand
+        const int slot = q * 64 + lane;
+        s_valid[j] = true;
         int r, c;
         if (is_g) {
             constexpr int CPR = BM / 8;
@@ -431,9 +423,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
         unsigned char* base = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const int q = wave + 4 * j;
-            if (q >= PIECES) continue;               // wave-uniform
-            const bool is_g = q < PIECES_G;
+            const bool is_g = j < PER_G;                                   // compile-time after unrolling
+            const int q = is_g ? (wave + 4 * j) % PIECES_G : PIECES_G + (wave + 4 * (j - PER_G)) % PIECES_X;
             const int sH = is_g ? p.YH : p.IH, sW = is_g ? p.YW : p.IW, sC = is_g ? p.Cout : p.Cin;
             int iy = w_oy[j] * (is_g ? p.osy : p.sy) + s_yoff[j];
             int ix = w_ox[j] * (is_g ? p.osx : p.sx) + s_xoff[j];
@@ -441,7 +432,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
             if (REFLECT && !is_g) { iy = reflect_coord(iy, sH); ix = reflect_coord(ix, sW); }
             else ok = ok && (unsigned)iy < (unsigned)sH && (unsigned)ix < (unsigned)sW;
             const unsigned off = (unsigned)(((w_b[j] * sH + iy) * sW + ix) * sC) * 2u + s_cb[j];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(is_g ? rg : rx, LDS_PTR(base + q * 1024), 16, (int)(ok ? off : 0xffffffffu), 0, 0, 0);
+            if (is_g) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, LDS_PTR(base + q * 1024), 16, (int)(ok ? off : 0xffffffffu), 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + q * 1024), 16, (int)(ok ? off : 0xffffffffu), 0, 0, 0);
             // advance 32 pixels
             w_p[j] += 32;
             w_ox[j] += d_ox;
@@ -490,30 +482,59 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
 #pragma unroll
             for (int h = 0; h < 2; ++h) b_addr[b][s][h] = 32 * BM * 2 + tr_addr(0, wn * NT + b, s, h);
 
-    auto tr_read = [&](const unsigned char* base, int off0, int off1) -> bf16x8 {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + off0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(base + off1));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
+    // The transpose reads are issued through inline asm: for the __builtin_amdgcn_ds_read_tr16_b64 form hipcc (ROCm 7.2) puts an
+    // s_waitcnt vmcnt(0) in front of the first read of every step (it orders the read behind ALL pending LDS-DMA), which drains
+    // the pipeline the counted wait above keeps full.  The asm form is opaque to that pass; the data hazard is handled by hand:
+    // one s_waitcnt lgkmcnt(0) + sched_barrier before the MFMAs (cdna_hip_programming.md §5.4 rule 18).
+    const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+    auto tr_ld = [&](unsigned addr) -> s16x4 {
+        s16x4 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
     };
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
 
     const int nsteps = (pend - pbeg + 31) / 32;
-    dma(0);
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) dma(st);    // prologue: steps 0 .. NST-2 (past pend: zero fill)
+    int st_cur = 0, st_free = NST - 1;
     for (int s_ = 0; s_ < nsteps; ++s_) {
-        const int buf = s_ & 1;
-        dma(buf ^ 1);                                // past pend: zero fill (never multiplied into anything that matters)
-        const unsigned char* base = smem + buf * BUF;
+        wait_vmcnt<(NST - 2) * PER>();               // this wave's pieces of step s_ have landed
+        __builtin_amdgcn_s_barrier();                // ... and everybody else's; all waves are done with step s_-1
+        dma(st_free);
+        const unsigned sbase = lds0 + (unsigned)(st_cur * BUF);
+        s16x4 ra[MT][2][2], rb_[NT][2][2];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) ra[a][s][h] = tr_ld(sbase + (unsigned)a_addr[a][s][h]);
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) rb_[b][s][h] = tr_ld(sbase + (unsigned)b_addr[b][s][h]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         bf16x8 fa[MT][2], fb[NT][2];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) fa[a][s] = tr_read(base, a_addr[a][s][0], a_addr[a][s][1]);
+            for (int s = 0; s < 2; ++s) {
+                const s16x8 v = {ra[a][s][0][0], ra[a][s][0][1], ra[a][s][0][2], ra[a][s][0][3],
+                                 ra[a][s][1][0], ra[a][s][1][1], ra[a][s][1][2], ra[a][s][1][3]};
+                fa[a][s] = __builtin_bit_cast(bf16x8, v);
+            }
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) fb[b][s] = tr_read(base, b_addr[b][s][0], b_addr[b][s][1]);
+            for (int s = 0; s < 2; ++s) {
+                const s16x8 v = {rb_[b][s][0][0], rb_[b][s][0][1], rb_[b][s][0][2], rb_[b][s][0][3],
+                                 rb_[b][s][1][0], rb_[b][s][1][1], rb_[b][s][1][2], rb_[b][s][1][3]};
+                fb[b][s] = __builtin_bit_cast(bf16x8, v);
+            }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -521,8 +542,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
 #pragma unroll
                 for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
-        __syncthreads();
+        st_free = st_cur;
+        st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
     }
+    wait_vmcnt<0>();
 
     // ---- epilogue: D rows = output channels (r&3) + 8 (r>>2) + 4 lh of block a, column = k column li of block b ------------
 #pragma unroll
@@ -594,8 +617,8 @@ int launch_bf16_wgrad_cfg(float* gw, const void* gy, const void* x, const float*
 extern "C" int ideas_bf16_conv_supported(const ideas_conv_params* p, int scaled) {
     if (!p) return 0;
     if (p->Cin % 32 || p->Cout % 4 || p->TY * p->TX > 32) return 0;
-    if ((int64_t)p->B * p->IH * p->IW * p->Cin * 2 >= 0xffffffffLL || (int64_t)p->TY * p->TX * p->Cin * p->Cout * 2 >= 0x7fffffffLL) return 0;
-    (void)scaled;
+    if ((int64_t)p->B * p->IH * p->IW * p->Cin * 2 >= 0xffffffffLL) return 0;
+    if ((int64_t)(scaled ? p->B : 1) * p->TY * p->TX * p->Cin * p->Cout * 2 >= 0xffffffffLL) return 0;   // (all per-sample packs)
     return 1;
 }
 
@@ -611,23 +634,25 @@ extern "C" int ideas_bf16_wgrad_supported(const ideas_conv_params* p, int scaled
     return 1;
 }
 
-extern "C" int ideas_bf16_pack_weights(void* pack, const void* wmat, int Cout, int K, int Cin, void* stream_) {
+extern "C" int ideas_bf16_pack_weights(void* pack, const void* wmat, const float* in_scale, int B, int Cout, int K, int Cin,
+                                       void* stream_) {
     if (!pack || !wmat) return IDEAS_E_NULL;
-    if (Cout <= 0 || K <= 0 || Cin <= 0 || K % Cin) return IDEAS_E_SHAPE;
-    if (Cin % 32 || !ideas_aligned16(pack) || !ideas_aligned16(wmat)) return IDEAS_E_ALIGN;
+    if (Cout <= 0 || K <= 0 || Cin <= 0 || K % Cin || B <= 0 || B > 65535) return IDEAS_E_SHAPE;
+    if (Cin % 32 || !ideas_aligned16(pack) || !ideas_aligned16(wmat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
+    if (!in_scale && B != 1) return IDEAS_E_SHAPE;
     const int64_t n8 = (int64_t)Cout * (K / 8);
     const int blocks = (int)(n8 / 256 + 1 < 2048 ? n8 / 256 + 1 : 2048);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint4*)pack, (const float4*)wmat,
-                       Cout, K, Cin);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, in_scale ? B : 1), dim3(256), 0, (hipStream_t)stream_, (uint4*)pack,
+                       (const float4*)wmat, in_scale, Cout, K, Cin);
     return ideas_launch_status();
 }
 
 // called by ideas_conv_igemm / ideas_conv_wgrad for dtype IDEAS_BF16 once the arguments are validated
-int ideas_bf16_fwd(void* y, const void* x, const void* wpack, const float* in_scale, const float* out_scale, const float* bias,
+int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                    const void* resid, const ideas_conv_params* p, hipStream_t stream) {
-    if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, in_scale, out_scale, bias, resid, p, stream);   // 128 x 128
-    if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, in_scale, out_scale, bias, resid, p, stream);   // 128 x 64
-    return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, in_scale, out_scale, bias, resid, p, stream);                     // 128 x 32
+    if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 128
+    if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 64
+    return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);                     // 128 x 32
 }
 
 int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,

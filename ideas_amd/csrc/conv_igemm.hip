@@ -577,12 +577,13 @@ extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const 
     if (!y || !x || !wmat) return IDEAS_E_NULL;
     int rc = check_conv(p);
     if (rc) return rc;
-    if (dtype == IDEAS_BF16) {     // bf16 x / y / resid, wmat = pack of ideas_bf16_pack_weights, f32 scales and bias
+    if (dtype == IDEAS_BF16) {     // bf16 x / y / resid; wmat = pack(s) of ideas_bf16_pack_weights: with an in_scale pointer one pack
+                                   // PER SAMPLE made with that very scale (the pointer only selects the per-sample mode here)
         if (!ideas_bf16_conv_supported(p, in_scale != nullptr)) return IDEAS_E_UNSUPPORTED;
         if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || !ideas_aligned16(y) || (in_scale && !ideas_aligned16(in_scale)) ||
             (out_scale && !ideas_aligned16(out_scale)) || (bias && !ideas_aligned16(bias)) || (resid && !ideas_aligned16(resid)))
             return IDEAS_E_ALIGN;
-        return ideas_bf16_fwd(y, x, wmat, in_scale, out_scale, bias, resid, p, (hipStream_t)stream_);
+        return ideas_bf16_fwd(y, x, wmat, in_scale != nullptr, out_scale, bias, resid, p, (hipStream_t)stream_);
     }
     if (p->Cin % 4) return IDEAS_E_ALIGN;
     if (!ideas_aligned16(x) || !ideas_aligned16(wmat) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;

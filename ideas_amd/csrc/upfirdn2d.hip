@@ -146,6 +146,136 @@ __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __
     }
 }
 
+// ---------------- bf16 NHWC 4x4 blur, 8 channels (16 bytes) per thread -------------------------------------------------
+// With 2-byte elements the 4-channel window kernel above moves half the bytes per instruction and is latency-bound
+// (1.45 TB/s measured).  Here a thread owns 8 channels of one output column.  A 4x4 window of 8-channel inputs would be 128
+// registers, so the kernel uses that every FIR on the path is an outer product kv (x) kh (make_kernel, stylegan2/model.py:22-30):
+// each input row is reduced to ONE horizontally filtered row of 8 floats as it arrives, and the window is four of those.
+// The factorisation is checked on the device from the 16 taps; a FIR that is not rank 1 takes the direct 16-tap loop.
+struct F8 { float v[8]; };
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    f[0] = __builtin_bit_cast(float, u.x << 16); f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, u.y << 16); f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    f[4] = __builtin_bit_cast(float, u.z << 16); f[5] = __builtin_bit_cast(float, u.z & 0xffff0000u);
+    f[6] = __builtin_bit_cast(float, u.w << 16); f[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(ideas_pk_bf16(f[0], f[1]), ideas_pk_bf16(f[2], f[3]), ideas_pk_bf16(f[4], f[5]), ideas_pk_bf16(f[6], f[7]));
+}
+
+__global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const uint4* __restrict__ x,
+                                                    const float* __restrict__ fir, FirParams p) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    float kh[4], kv[4];
+    float kmax = 0.f, res = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { kh[t] = sk[t]; kv[t] = sk[0] != 0.f ? sk[4 * t] / sk[0] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kmax = fmaxf(kmax, fabsf(sk[4 * j + t])); res = fmaxf(res, fabsf(sk[4 * j + t] - kv[j] * kh[t])); }
+    const bool sep = res <= 1e-6f * kmax;           // block-uniform
+
+    const int C8 = p.C >> 3;
+    const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * p.out_w * C8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int c8 = (int)(r % C8); r /= C8;
+    const int ox = (int)(r % p.out_w); r /= p.out_w;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int oy0 = seg * p.seg_rows;
+    const int oy1 = (oy0 + p.seg_rows < p.out_h) ? oy0 + p.seg_rows : p.out_h;
+    const int ix0 = ox - p.pad_x0;
+    const uint4* xb = x + (int64_t)b * p.in_h * p.in_w * C8 + c8;
+    uint4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C8 + c8;
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
+    // (component-wise masking: a ternary on the uint4 aggregate becomes a select between ADDRESSES and spills to scratch)
+    auto load_row = [&](int iy, uint4 (&dst)[4]) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const int iyc = rowok ? iy : 0;
+        const uint4* xr = xb + (int64_t)iyc * p.in_w * C8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = rowok && ((colmask >> t) & 1u);
+            const int ixc = ok ? ix0 + t : 0;                      // clamped: always a valid address
+            const uint4 v = xr[(int64_t)ixc * C8];
+            const unsigned m = ok ? 0xffffffffu : 0u;
+            dst[t] = make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+        }
+    };
+    if (!sep) {      // direct 16-tap form (no window): correct for any FIR, not tuned
+#pragma unroll 1
+        for (int oy = oy0; oy < oy1; ++oy) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                uint4 row[4];
+                load_row(oy - p.pad_y0 + j, row);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float f[8];
+                    unpack8(row[t], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(f[e], sk[4 * j + t], acc[e]);
+                }
+            }
+            yb[(int64_t)oy * p.out_w * C8] = pack8(acc);
+        }
+        return;
+    }
+    auto hfilter = [&](const uint4 (&row)[4], F8& h) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h.v[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float f[8];
+            unpack8(row[t], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h.v[e] = fmaf(f[e], kh[t], h.v[e]);
+        }
+    };
+    auto emit = [&](int oy, const F8& a0, const F8& a1, const F8& a2, const F8& a3) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a0.v[e] * kv[0] + a1.v[e] * kv[1] + a2.v[e] * kv[2] + a3.v[e] * kv[3];
+        yb[(int64_t)oy * p.out_w * C8] = pack8(o);
+    };
+    F8 h0, h1, h2, h3, h4;
+    {
+        uint4 r0[4], r1[4], r2[4];
+        const int iy0 = oy0 - p.pad_y0;
+        load_row(iy0 + 0, r0); load_row(iy0 + 1, r1); load_row(iy0 + 2, r2);
+        hfilter(r0, h0); hfilter(r1, h1); hfilter(r2, h2);
+    }
+    int oy = oy0;
+#pragma unroll 1
+    for (; oy + 1 < oy1; oy += 2) {      // two output rows per trip: eight 16-byte loads in flight
+        uint4 ra[4], rb[4];
+        load_row(oy - p.pad_y0 + 3, ra);
+        load_row(oy - p.pad_y0 + 4, rb);
+        hfilter(ra, h3); hfilter(rb, h4);
+        emit(oy, h0, h1, h2, h3);
+        emit(oy + 1, h1, h2, h3, h4);
+        h0 = h2; h1 = h3; h2 = h4;
+    }
+    if (oy < oy1) {
+        uint4 ra[4];
+        load_row(oy - p.pad_y0 + 3, ra);
+        hfilter(ra, h3);
+        emit(oy, h0, h1, h2, h3);
+    }
+}
+
 // ---------------- NCHW tiled blur, up = down = 1, k <= 4 -------------------------------------------
 #define TNH 16
 #define TNW 64
@@ -216,7 +346,11 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
         const int64_t total = (int64_t)B * segs * out_w * (C / 4);
         const int64_t grid = ideas_cdiv(total, 256);
         if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
-        if (dtype == IDEAS_BF16)
+        if (dtype == IDEAS_BF16 && C % 8 == 0) {
+            const int64_t total8 = (int64_t)B * segs * out_w * (C / 8);
+            hipLaunchKernelGGL(blur4_bf16x8, dim3((unsigned)ideas_cdiv(total8, 256)), dim3(256), 0, stream, (uint4*)y,
+                               (const uint4*)x, fir, p);
+        } else if (dtype == IDEAS_BF16)
             hipLaunchKernelGGL(blur4_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
                                (const ideas_bf16x4*)x, fir, p);
         else

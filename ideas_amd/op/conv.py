@@ -93,16 +93,21 @@ def _f32(t):
     return None if t is None else t.float()
 
 
-def bf16_pack(L: Launch, w: torch.Tensor) -> torch.Tensor:
-    """bf16 pack of a forward-family weight matrix for ideas_conv_igemm(IDEAS_BF16), memoised like the b3 planes."""
+def bf16_pack(L: Launch, w: torch.Tensor, in_scale=None) -> torch.Tensor:
+    """bf16 pack of a forward-family weight matrix for ideas_conv_igemm(IDEAS_BF16).  Plain convs: one pack, memoised like
+    the b3 planes.  Modulated convs (in_scale [B, Cin]): one pack per sample, w * in_scale[b] — never cached (it depends on
+    the styles) and freed after the launch."""
     k = L.TY * L.TX * L.Cin
+    nb = 1 if in_scale is None else L.B
 
     def make():
-        pk = torch.empty(L.Cout * k, device=w.device, dtype=BF)
-        _lib.check(_lib.load().ideas_bf16_pack_weights(_lib.ptr(pk), _lib.ptr(w), L.Cout, k, L.Cin, _lib.stream_ptr()),
-                   "ideas_bf16_pack_weights")
+        pk = torch.empty(nb * L.Cout * k, device=w.device, dtype=BF)
+        _lib.check(_lib.load().ideas_bf16_pack_weights(_lib.ptr(pk), _lib.ptr(w), _lib.ptr(in_scale), nb, L.Cout, k, L.Cin,
+                                                        _lib.stream_ptr()), "ideas_bf16_pack_weights")
         return pk
-    return conv_plan.cached(L.wsrc, ("bf16",) + L.wkey, make) if L.wsrc is not None else make()
+    if in_scale is not None or L.wsrc is None:
+        return make()
+    return conv_plan.cached(L.wsrc, ("bf16",) + L.wkey, make)
 
 
 def _params(L: Launch, gain: float, accumulate: bool = False, act: bool = False, alpha: float = 0.2,
@@ -123,7 +128,7 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
         w = w.contiguous()
     if x.dtype == BF:
         if lib.ideas_bf16_conv_supported(C.byref(p), int(in_scale is not None)):
-            rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bf16_pack(L, w)), _lib.ptr(in_scale), _lib.ptr(out_scale),
+            rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bf16_pack(L, w, in_scale)), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.BF16, _lib.stream_ptr())
             _lib.check(rc, "ideas_conv_igemm[bf16]")
             return

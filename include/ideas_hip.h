@@ -151,10 +151,14 @@ int ideas_b3_wino_split_weights(void* planes, const void* w, int N, int C, int64
  *   ideas_bf16_pack_weights     wmat f32 [Cout][K] (K = taps*Cin, the matrix ideas_conv_igemm takes for IDEAS_F32) -> `pack`,
  *                               Cout*K bf16 laid out [K/32][Cout][32], K-steps ordered (ci/32, ty, tx), 16-byte chunk c of row
  *                               n stored at position c ^ ((n >> 2) & 3) (the LDS swizzle, so the kernel's DMA is linear).
- *                               With IDEAS_BF16 the `wmat` argument of ideas_conv_igemm is this buffer. */
+ *                               in_scale == NULL: one pack (B must be 1).  in_scale = float[B][Cin] (modulated conv): B packs,
+ *                               pack b = bf16(w[n][k] * in_scale[b][ci(k)]) -- the reference's per-sample weights
+ *                               (stylegan2/model.py:240-248) for the life of one launch.
+ *                               With IDEAS_BF16 the `wmat` argument of ideas_conv_igemm is this buffer; pass the same in_scale
+ *                               to ideas_conv_igemm (it selects the per-sample packs; the scale itself is already applied). */
 int ideas_bf16_conv_supported(const ideas_conv_params* p, int scaled);
 int ideas_bf16_wgrad_supported(const ideas_conv_params* p, int scaled);
-int ideas_bf16_pack_weights(void* pack, const void* wmat, int Cout, int K, int Cin, void* stream);
+int ideas_bf16_pack_weights(void* pack, const void* wmat, const float* in_scale, int B, int Cout, int K, int Cin, void* stream);
 /* 1 if ideas_conv_direct / ideas_conv_wgrad_direct with IDEAS_BF16 are the intended path for the geometry: the HBM-bound
  * pointwise layers with <= 8 input or output channels (from-RGB, to-RGB and their gradients).  Everything else without a bf16
  * MFMA kernel (a handful of tiny layers) is computed by the caller in f32 on casts. */

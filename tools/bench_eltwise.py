@@ -28,10 +28,12 @@ def timeit(fn, reps=20):
 
 
 def main():
+    adt = torch.bfloat16 if "--bf16" in sys.argv else torch.float32
+    es = 2 if adt == torch.bfloat16 else 4
     dev = torch.device("cuda")
     fir = make_kernel((1, 3, 3, 1)).to(dev)
     for (B, C, H) in ((32, 128, 256), (96, 128, 256), (32, 256, 128), (32, 512, 64), (96, 64, 256), (256, 64, 64)):
-        x = torch.randn(B, C, H, H, device=dev).contiguous(memory_format=CL)
+        x = torch.randn(B, C, H, H, device=dev).to(adt).contiguous(memory_format=CL)
         b = torch.randn(C, device=dev)
         n = x.numel()
         y = bias_act_raw(x, b, None, 0, 0.2, 1.4)
@@ -43,7 +45,7 @@ def main():
         ms6 = timeit(lambda: act_bwd_dot(x, y, b, 0.2, 1.4))
         ms7 = timeit(lambda: torch.add(x, y))
         ms8 = timeit(lambda: x * 0.7)
-        gb = n * 4 / 1e9
+        gb = n * es / 1e9
         print(f"[{B},{C},{H},{H}] {gb:6.2f} GB | act fwd {2 * gb / ms * 1e3:6.0f} GB/s | act bwd+bias {3 * gb / ms2 * 1e3:6.0f} | "
               f"blur(2,2) {2 * gb / ms3 * 1e3:6.0f} | blur(1,1) {2 * gb / ms4 * 1e3:6.0f} | pixel_dot {2 * gb / ms5 * 1e3:6.0f} | "
               f"act_bwd_dot {3 * gb / ms6 * 1e3:6.0f} | torch add {3 * gb / ms7 * 1e3:6.0f} | torch mul {2 * gb / ms8 * 1e3:6.0f}", flush=True)

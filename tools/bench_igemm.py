@@ -53,9 +53,13 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: same work, lower power)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="activation dtype (bf16: csrc/conv_bf16.hip)")
     a = ap.parse_args()
+    adt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda")
     tot_f = tot_t = 0.0
+    from ideas_amd.op import conv_plan
+    conv_plan.cache_begin()          # as inside train_iteration: derived weights (split planes / bf16 packs) are made once
     for (name, ci, co, k, s, p, refl, H, bm, mod, kind) in SHAPES:
         if a.only and a.only not in name:
             continue
@@ -64,10 +68,10 @@ def main():
         if a.zeros:
             torch.randn = lambda *sh, **kw: torch.zeros(*sh, **kw)
         if kind == "conv":
-            x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=CL)
-            w = torch.randn(co, ci, k, k, device=dev).contiguous(memory_format=CL)
+            x = torch.randn(B, ci, H, H, device=dev).to(adt).contiguous(memory_format=CL)
+            w = torch.nn.Parameter(torch.randn(co, ci, k, k, device=dev).contiguous(memory_format=CL))
             oh, ow = g.out_size(H, H)
-            gy = torch.randn(B, co, oh, ow, device=dev).contiguous(memory_format=CL)
+            gy = torch.randn(B, co, oh, ow, device=dev).to(adt).contiguous(memory_format=CL)
             lin = (torch.rand(B, ci, device=dev) + 0.5) if mod else None
             lout = (torch.rand(B, co, device=dev) + 0.5) if mod else None
             flops = 2.0 * B * oh * ow * ci * co * k * k
@@ -77,10 +81,10 @@ def main():
                 "wgrad": lambda: conv_wgrad_raw(gy, x, g, w.shape, 0.1, lin, lout),
             }
         else:  # transposed conv: weight read as conv weight [O'=ci, I'=co]
-            x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=CL)
-            wt = torch.randn(ci, co, k, k, device=dev).contiguous(memory_format=CL)
+            x = torch.randn(B, ci, H, H, device=dev).to(adt).contiguous(memory_format=CL)
+            wt = torch.nn.Parameter(torch.randn(ci, co, k, k, device=dev).contiguous(memory_format=CL))
             oh, ow = convT_out_size(H, H, g)
-            gy = torch.randn(B, co, oh, ow, device=dev).contiguous(memory_format=CL)
+            gy = torch.randn(B, co, oh, ow, device=dev).to(adt).contiguous(memory_format=CL)
             lin = (torch.rand(B, ci, device=dev) + 0.5) if mod else None
             lout = (torch.rand(B, co, device=dev) + 0.5) if mod else None
             flops = 2.0 * B * H * H * ci * co * k * k
