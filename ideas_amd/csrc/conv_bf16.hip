@@ -98,20 +98,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int MT, int NT, bool PERIMG, bool REFLECT>
-__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+template <int WM, int WN, int MT, int NT, int NST, bool PERIMG, bool REFLECT>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
                                                            const void* __restrict__ wpack, const float* __restrict__ out_scale,
                                                            const float* __restrict__ bias, const bf16_t* __restrict__ resid,
                                                            ideas_conv_params p, int tiles_n, int tiles_per_img, unsigned x_bytes,
                                                            unsigned w_bytes) {
-    static_assert(WM * WN == 4, "4 waves per block");
-    constexpr int NST = 3;
+    constexpr int NW = WM * WN;           // waves per block (4 or 8)
     constexpr int BM = WM * MT * 32;      // pixels of the tile
     constexpr int BN = WN * NT * 32;      // output channels of the tile
-    static_assert(BM % 64 == 0, "each wave issues whole 16-row DMA pieces");
-    constexpr int A_PER = BM / 64;        // 16-row DMA pieces of the A tile per wave
-    constexpr int B_PIECES = BN / 16;     // 16-row pieces of the B tile
-    constexpr int B_PER = (B_PIECES + 3) / 4;
+    constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;     // 16-row (1 KiB) DMA pieces per tile
+    constexpr int A_PER = (A_PIECES + NW - 1) / NW;           // per wave; a wave without a piece of its own repeats one
+    constexpr int B_PER = (B_PIECES + NW - 1) / NW;
     constexpr int DMA_PER = A_PER + B_PER;
     constexpr int BUF = (BM + BN) * ROW;
     constexpr int SMEM = NST * BUF > BM * 12 ? NST * BUF : BM * 12;
@@ -142,7 +140,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
     int a_iyb[A_PER], a_ixb[A_PER], a_img[A_PER], a_c8[A_PER];
 #pragma unroll
     for (int j = 0; j < A_PER; ++j) {
-        const int r = (wave + 4 * j) * 16 + (lane >> 2);
+        const int r = ((wave + NW * j) % A_PIECES) * 16 + (lane >> 2);
         const int c = (lane & 3) ^ ((r >> 2) & 3);
         int64_t m = m0 + r;
         m = m < mend ? m : mend - 1;               // rows past the end repeat the last row; their results are not stored
@@ -181,13 +179,13 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
             } else {
                 off = (a_base[j] + tapoff) | (unsigned)__builtin_amdgcn_sbfe(a_inv[j], k_tap, 1);
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + (wave + 4 * j) * 1024), 16, (int)off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + ((wave + NW * j) % A_PIECES) * 1024), 16, (int)off, 0, 0, 0);
         }
         // (the K-step offset is folded into the per-lane offset: only that one is range-checked by a raw buffer)
         const unsigned soff = w_img + (unsigned)k_next * (unsigned)p.Cout * 64u;
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) {
-            const int q = (wave + 4 * j) % B_PIECES;        // narrow tiles: some waves repeat a piece (same bytes, same place)
+            const int q = (wave + NW * j) % B_PIECES;       // narrow tiles: some waves repeat a piece (same bytes, same place)
             unsigned off = soff + (unsigned)((n0 + q * 16) * 64 + lane * 16);
             off = off < w_end ? off : 0xffffffffu;          // past this image's pack (last tiles, rows >= Cout of the last step)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(base + BM * ROW + q * 1024), 16, (int)off, 0, 0, 0);
@@ -305,7 +303,7 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(bf16_t* __restrict__ 
     }
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int NST = 3>
 int launch_bf16_cfg(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                     const void* resid, const ideas_conv_params* p, hipStream_t stream) {
     constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
@@ -317,8 +315,8 @@ int launch_bf16_cfg(void* y, const void* x, const void* wpack, int per_image, co
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
     const unsigned w_bytes = (unsigned)((int64_t)(per_image ? p->B : 1) * p->TY * p->TX * p->Cin * p->Cout * 2);
     auto go = [&](auto pi, auto rf) {
-        hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, decltype(pi)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
-                           dim3(256), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack, out_scale, bias, (const bf16_t*)resid, *p, tn,
+        hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, NST, decltype(pi)::value, decltype(rf)::value>), dim3((unsigned)(tm * tn)),
+                           dim3(64 * WM * WN), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack, out_scale, bias, (const bf16_t*)resid, *p, tn,
                            tpi, x_bytes, w_bytes);
     };
     using T = std::true_type;
@@ -653,6 +651,22 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 128
     if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 64
     return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);                     // 128 x 32
+}
+
+// Tile-shape A/B for tools/bench_igemm.py --cfg (not part of the declared ABI; the production dispatch is ideas_bf16_fwd)
+extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* wpack, int per_image, const float* out_scale,
+                                   const float* bias, const void* resid, const ideas_conv_params* p, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    switch (cfg) {
+        case 0: return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128x128, 4 waves
+        case 1: return launch_bf16_cfg<2, 2, 2, 2, 4>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // + 4 stages
+        case 2: return launch_bf16_cfg<2, 2, 4, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x128, 4 waves
+        case 3: return launch_bf16_cfg<4, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x128, 8 waves
+        case 4: return launch_bf16_cfg<2, 4, 4, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x256, 8 waves
+        case 5: return launch_bf16_cfg<2, 2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 2 stages
+        case 6: return launch_bf16_cfg<2, 2, 2, 4, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128x256, 4 waves
+        default: return IDEAS_E_UNSUPPORTED;
+    }
 }
 
 int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
