@@ -178,6 +178,145 @@ __global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __res
     }
 }
 
+// ---- pointwise layers with one WIDE and one tiny channel count: 16-byte vector access along the wide axis ---------------
+// to_rgb (128 -> 3), the input gradient of the from-RGB convs (64 / 32 -> 3), the 8- / N-channel heads, and their weight
+// gradients.  They are pure streams over the wide tensor (1.6 GFLOP against 0.5 GB at B = 32), but the one-thread-per-output
+// kernels above read it with 2- / 4-byte accesses and ran at 0.2-0.5 TB/s (to_rgb forward: 2.4 ms in bf16).  Here a group of
+// L lanes owns one pixel, each lane VEC = 16 B / sizeof(T) consecutive channels (coalesced 16-byte loads, L * 16 contiguous
+// bytes per pixel), the tiny axis lives in registers, and the L partial sums meet through wave shuffles.
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<bf16_t> { static constexpr int N = 8; };
+__device__ __forceinline__ void ldvec(const float* p, float (&f)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+__device__ __forceinline__ void ldvec(const bf16_t* p, float (&f)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    f[0] = __builtin_bit_cast(float, u.x << 16); f[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, u.y << 16); f[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    f[4] = __builtin_bit_cast(float, u.z << 16); f[5] = __builtin_bit_cast(float, u.z & 0xffff0000u);
+    f[6] = __builtin_bit_cast(float, u.w << 16); f[7] = __builtin_bit_cast(float, u.w & 0xffff0000u);
+}
+
+// y[p][o] = epilogue(sum_c x[p][c] w[o][c]),  Cout <= NS, Cin = L * VEC * IT
+template <typename T, int NS, int IT>
+__global__ __launch_bounds__(256) void pointwise_rowdot_kernel(T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, const T* __restrict__ resid, int64_t P,
+                                                               int Cin, int Cout, int L, float gain, int act, float alpha,
+                                                               float act_gain, float resid_gain, int accumulate) {
+    constexpr int VEC = VecOf<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (L - 1), grp = lane / L, G = 64 / L;        // lane within its pixel group, group within the wave
+    float wr[NS][IT][VEC];
+#pragma unroll
+    for (int o = 0; o < NS; ++o)
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) wr[o][it][e] = o < Cout ? w[(int64_t)o * Cin + (it * L + sub) * VEC + e] : 0.f;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p0 = wave * G; p0 < P; p0 += nwaves * G) {
+        const int64_t pp = p0 + grp;
+        const bool ok = pp < P;
+        const T* xp = x + (ok ? pp : P - 1) * Cin;
+        float acc[NS];
+#pragma unroll
+        for (int o = 0; o < NS; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            float f[VEC];
+            ldvec(xp + (it * L + sub) * VEC, f);
+#pragma unroll
+            for (int o = 0; o < NS; ++o)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[o] = fmaf(f[e], wr[o][it][e], acc[o]);
+        }
+        for (int m = 1; m < L; m <<= 1)
+#pragma unroll
+            for (int o = 0; o < NS; ++o) acc[o] += __shfl_xor(acc[o], m, 64);
+        if (ok && sub < Cout) {                       // lane `sub` of the group writes output channel `sub`
+            float a = acc[0];
+#pragma unroll
+            for (int o = 1; o < NS; ++o) a = sub == o ? acc[o] : a;
+            float v = mul_then_add(a, gain, bias ? bias[sub] : 0.f);
+            if (act) v = (v > 0.f ? v : v * alpha) * act_gain;
+            const int64_t yi = pp * Cout + sub;
+            if (resid) v = (v + ldv(resid + yi)) * resid_gain;
+            if (accumulate) v += ldv(y + yi);
+            stv(y + yi, v);
+        }
+    }
+}
+
+// gw += gain * sum_p S[p][s] * W[p][c]:  W = the wide tensor [P][Cw] (16-byte loads), S = the tiny one [P][Cs], Cs <= NS.
+// SMALL_IS_OUT: S = gy (Cs = Cout), W = x (Cw = Cin) -> gw[s][c];  otherwise S = x (Cs = Cin), W = gy (Cw = Cout) -> gw[c][s].
+template <typename T, int NS, int IT, bool SMALL_IS_OUT>
+__global__ __launch_bounds__(256) void pointwise_wgrad_vec_kernel(float* __restrict__ gw, const T* __restrict__ S, const T* __restrict__ W,
+                                                                  int64_t P, int Cs, int Cw, int L, float gain, int64_t pix_per_block) {
+    constexpr int VEC = VecOf<T>::N;
+    extern __shared__ float s_red[];                 // [Cs][Cw] block partial sums
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane & (L - 1), grp = lane / L, G = 64 / L;
+    for (int i = threadIdx.x; i < Cs * Cw; i += blockDim.x) s_red[i] = 0.f;
+    __syncthreads();
+    float acc[NS][IT][VEC];
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[s_][it][e] = 0.f;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
+    for (int64_t pp = p0 + wv * G + grp; pp < p1; pp += 4 * G) {
+        float sv[NS];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) sv[s_] = s_ < Cs ? ldv(S + pp * Cs + s_) : 0.f;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            float f[VEC];
+            ldvec(W + pp * Cw + (it * L + sub) * VEC, f);
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[s_][it][e] = fmaf(sv[s_], f[e], acc[s_][it][e]);
+        }
+    }
+    // fold the pixel groups of the wave (lanes with equal `sub`), then the waves through LDS, then one atomic per element
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_)
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float v = acc[s_][it][e];
+                for (int m = L; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+                if (grp == 0 && s_ < Cs) atomicAdd(&s_red[s_ * Cw + (it * L + sub) * VEC + e], v);
+            }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cs * Cw; i += blockDim.x) {
+        const int s_ = i / Cw, c = i % Cw;
+        const int64_t dst = SMALL_IS_OUT ? (int64_t)s_ * Cw + c : (int64_t)c * Cs + s_;
+        atomicAdd(&gw[dst], s_red[i] * gain);
+    }
+}
+
+// (L, IT) with wide = L * VEC * IT, L a power of two <= 64, IT <= 4; false if the wide axis does not decompose that way
+template <typename T>
+bool vec_split(int wide, int& L, int& IT) {
+    constexpr int VEC = VecOf<T>::N;
+    if (wide % VEC) return false;
+    const int chunks = wide / VEC;
+    for (IT = 1; IT <= 4; ++IT) {
+        if (chunks % IT) continue;
+        L = chunks / IT;
+        if (L <= 64 && L >= 1 && (L & (L - 1)) == 0) return true;
+    }
+    return false;
+}
+
 bool is_pointwise(const ideas_conv_params* p) {
     return p->TY == 1 && p->TX == 1 && p->sy == 1 && p->sx == 1 && p->offy == 0 && p->offx == 0 && p->osy == 1 &&
            p->osx == 1 && p->ooy == 0 && p->oox == 0 && p->IH == p->OH && p->IW == p->OW && p->YH == p->OH && p->YW == p->OW;
@@ -195,6 +334,22 @@ int check_conv(const ideas_conv_params* p) {
 template <typename T>
 int conv_direct_impl(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale, const float* bias,
                      const void* resid, const ideas_conv_params* p, void* stream) {
+    int L = 0, IT = 0;
+    if (is_pointwise(p) && !in_scale && !out_scale && p->Cout <= 8 && p->Cin >= 32 && vec_split<T>(p->Cin, L, IT) && p->Cout <= L &&
+        ideas_aligned16(x)) {
+        const int64_t P = (int64_t)p->B * p->OH * p->OW;
+        int64_t grid = ideas_cdiv(P, (int64_t)(64 / L) * 4 * 4);
+        if (grid > 4096) grid = 4096;
+        if (grid < 1) grid = 1;
+#define ROWDOT(NS_, IT_)                                                                                                              \
+    hipLaunchKernelGGL((pointwise_rowdot_kernel<T, NS_, IT_>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (T*)y,       \
+                       (const T*)x, (const float*)wmat, bias, (const T*)resid, P, p->Cin, p->Cout, L, p->gain, p->act, p->alpha,      \
+                       p->act_gain, p->resid_gain, p->accumulate)
+        if (p->Cout <= 4) { if (IT == 1) ROWDOT(4, 1); else if (IT == 2) ROWDOT(4, 2); else if (IT == 3) ROWDOT(4, 3); else ROWDOT(4, 4); }
+        else { if (IT == 1) ROWDOT(8, 1); else if (IT == 2) ROWDOT(8, 2); else if (IT == 3) ROWDOT(8, 3); else ROWDOT(8, 4); }
+#undef ROWDOT
+        return ideas_launch_status();
+    }
     if (is_pointwise(p) && !in_scale && !out_scale && p->Cin <= 8 && p->Cout <= 256) {
         const int64_t P = (int64_t)p->B * p->OH * p->OW;
         const int groups = 256 / p->Cout;
@@ -218,6 +373,27 @@ template <typename T>
 int wgrad_direct_impl(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                       const ideas_conv_params* p, void* stream) {
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
+    {
+        // wide/tiny pointwise layers: vector kernel (tiny axis <= 4, wide axis >= 32 and decomposable)
+        const bool small_out = p->Cout <= p->Cin;
+        const int Cs = small_out ? p->Cout : p->Cin, Cw = small_out ? p->Cin : p->Cout;
+        int L = 0, IT = 0;
+        if (is_pointwise(p) && !in_scale && !out_scale && Cs <= 4 && Cw >= 32 && Cw <= 512 && vec_split<T>(Cw, L, IT) && IT <= 2 &&
+            ideas_aligned16(small_out ? x : gy)) {
+            int64_t blocks = ideas_cdiv(P, 2048);
+            if (blocks > 2048) blocks = 2048;
+            const int64_t per = ideas_cdiv(P, blocks);
+            blocks = ideas_cdiv(P, per);
+            const size_t lds = (size_t)Cs * Cw * sizeof(float);
+#define WGV(IT_, SO_)                                                                                                                 \
+    hipLaunchKernelGGL((pointwise_wgrad_vec_kernel<T, 4, IT_, SO_>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, gw, \
+                       (const T*)(SO_ ? gy : x), (const T*)(SO_ ? x : gy), P, Cs, Cw, L, p->gain, per)
+            if (small_out) { if (IT == 1) WGV(1, true); else WGV(2, true); }
+            else { if (IT == 1) WGV(1, false); else WGV(2, false); }
+#undef WGV
+            return ideas_launch_status();
+        }
+    }
     if (is_pointwise(p) && !in_scale && !out_scale && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256) {
         int64_t blocks = ideas_cdiv(P, 512);
         if (blocks > 1024) blocks = 1024;
@@ -248,7 +424,7 @@ extern "C" int ideas_conv_check_params(const ideas_conv_params* p) { return chec
  * and their gradients); everything else without an MFMA bf16 kernel is computed in f32 by the caller. */
 extern "C" int ideas_bf16_direct_supported(const ideas_conv_params* p) {
     if (!p || check_conv(p)) return 0;
-    return is_pointwise(p) && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256;
+    return is_pointwise(p) && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 512 && p->Cout <= 512;
 }
 
 extern "C" int ideas_conv_direct(void* y, const void* x, const void* wmat, const float* in_scale, const float* out_scale,

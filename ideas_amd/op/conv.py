@@ -465,6 +465,7 @@ class _ConvBiasAct(Function):
         x = _nhwc(x)
         y = conv_fwd_raw(x, w, g, gain, bias=b.contiguous(), act=True, act_gain=act_gain, alpha=slope)
         ctx.g, ctx.gain, ctx.slope, ctx.act_gain = g, gain, slope, act_gain
+        ctx.bias_ref = b
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -472,13 +473,18 @@ class _ConvBiasAct(Function):
     def backward(ctx, gy):
         from .fused_act import FusedLeakyReLUFunctionBackward
         x, w, y = ctx.saved_tensors
-        g_pre, gb = FusedLeakyReLUFunctionBackward.apply(gy, y, ctx.slope, ctx.act_gain, True)
+        from .fused_act import bias_act_raw, bias_sink
+        tgt = bias_sink(ctx.bias_ref) if ctx.needs_input_grad[2] else None
+        if tgt is not None:          # gradient sink: bias gradient accumulated by the kernel into bias.grad
+            g_pre, gb = bias_act_raw(gy, None, y, 1, ctx.slope, ctx.act_gain, bias_grad_into=tgt)
+        else:
+            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(gy, y, ctx.slope, ctx.act_gain, True)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(g_pre, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
         if ctx.needs_input_grad[1]:
             gw = _wgrad(w, g_pre, x, ctx.g, ctx.gain)
-        return gx, gw, (gb if ctx.needs_input_grad[2] else None), None, None, None, None
+        return gx, gw, (gb if (ctx.needs_input_grad[2] and tgt is None) else None), None, None, None, None
 
 
 def conv2d_bias_act(input: torch.Tensor, weight: torch.Tensor, act_bias: torch.Tensor, stride: int = 1, padding: int = 0,

@@ -40,8 +40,11 @@ def _layout_of(x: torch.Tensor):
 
 
 def bias_act_raw(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[torch.Tensor], grad: int,
-                 alpha: float, scale: float, want_bias_grad: bool = False, act: int = 3):
-    """One launch of ``ideas_fused_bias_act``; returns ``y`` or ``(y, bias_grad)``."""
+                 alpha: float, scale: float, want_bias_grad: bool = False, act: int = 3,
+                 bias_grad_into: Optional[torch.Tensor] = None):
+    """One launch of ``ideas_fused_bias_act``; returns ``y`` or ``(y, bias_grad)``.  ``bias_grad_into`` (a contiguous f32 [C]
+    tensor, e.g. the bias parameter's ``.grad`` view of the flat bucket): the kernel ADDS the bias gradient to it instead of
+    filling a fresh zeroed buffer (no allocation, no fill, no later accumulate pass); the second return value is then None."""
     _lib.require_cuda(x, bias, ref)
     dt = _lib.act_dtype(x)
     lib = _lib.load()
@@ -69,13 +72,27 @@ def bias_act_raw(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[to
             raise RuntimeError(f"fused_bias_act: bias has {bias.numel()} elements, expected {c}")
         bias = bias.contiguous().to(torch.float32)
     y = torch.empty_like(x)
-    bg = torch.zeros(c, device=x.device, dtype=torch.float32) if want_bias_grad else None
+    if bias_grad_into is not None:
+        bg, want_bias_grad = bias_grad_into, True
+    else:
+        bg = torch.zeros(c, device=x.device, dtype=torch.float32) if want_bias_grad else None
     if x.numel():
         rc = lib.ideas_fused_bias_act(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bias), _lib.ptr(ref), _lib.ptr(bg),
                                       x.numel(), c, inner, layout, act, grad, float(alpha), float(scale), dt,
                                       _lib.stream_ptr())
         _lib.check(rc, "ideas_fused_bias_act")
+    if bias_grad_into is not None:
+        return y, None
     return (y, bg) if want_bias_grad else y
+
+
+def bias_sink(bias: Optional[torch.Tensor]):
+    """Inside ``grad_sink`` (op/conv.py) and a plain backward: the bias parameter's gradient buffer to accumulate into."""
+    if bias is None:
+        return None
+    from .conv import _sink_target
+    tgt = _sink_target(bias)
+    return tgt if (tgt is not None and tgt.dim() == 1 and tgt.is_contiguous()) else None
 
 
 class FusedLeakyReLUFunctionBackward(Function):
@@ -108,11 +125,16 @@ class FusedLeakyReLUFunction(Function):
         out = bias_act_raw(input, bias, None, 0, negative_slope, scale)
         ctx.save_for_backward(out)
         ctx.negative_slope, ctx.scale, ctx.has_bias = negative_slope, scale, bias is not None
+        ctx.bias_ref = bias
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
         (out,) = ctx.saved_tensors
+        tgt = bias_sink(ctx.bias_ref) if ctx.has_bias else None
+        if tgt is not None:          # gradient sink: the kernel adds the bias gradient straight into bias.grad
+            grad_input, _ = bias_act_raw(grad_output, None, out, 1, ctx.negative_slope, ctx.scale, bias_grad_into=tgt)
+            return grad_input, None, None, None
         grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale,
                                                                       ctx.has_bias)
         return grad_input, (grad_bias if ctx.has_bias else None), None, None

@@ -25,6 +25,7 @@ from .. import _lib
 from ..precision import to_act, to_f32
 from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, weight_grad, _nhwc
 from .conv_plan import ConvGeom, convT_out_size
+from . import scratch
 from .upfirdn2d import upfirdn2d
 from .fused_act import fused_leaky_relu
 
@@ -33,7 +34,7 @@ def pixel_dot(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     """out[b,c] = sum over pixels of a[b,c,h,w]*g[b,c,h,w] (both NHWC in memory)."""
     a, g = _nhwc(a), _nhwc(g)
     b, c, h, w = a.shape
-    out = torch.zeros((b, c), device=a.device, dtype=torch.float32)
+    out = scratch.zeros((b, c), a.device)          # consumed (divided into a new tensor) before the caller returns
     if a.dtype != g.dtype:
         a, g = a.float(), g.float()
     if a.dtype == torch.bfloat16 and c % 4:
@@ -122,20 +123,21 @@ class _ModConv(Function):
         return (gx if need_x else None), gw, gs, gd, None, None
 
 
-def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: float, act_gain: float):
-    """(g_pre, bias_grad[C], dot[B,C]) from the incoming gradient and the saved post-activation output."""
+def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: float, act_gain: float, bias_grad_into=None):
+    """(g_pre, bias_grad[C], dot[B,C]) from the incoming gradient and the saved post-activation output.  ``bias_grad_into``: add
+    the bias gradient into that f32 [C] buffer (the parameter's .grad) instead of returning a fresh one (returns None for it)."""
     gy, out = _nhwc(gy), _nhwc(out)
     if gy.dtype != out.dtype:
         gy = gy.to(out.dtype)
     b, c, h, w = out.shape
     gpre = torch.empty_like(out)
-    bg = torch.zeros(c, device=out.device, dtype=torch.float32)
-    dot = torch.zeros((b, c), device=out.device, dtype=torch.float32)
+    bg = bias_grad_into if bias_grad_into is not None else torch.zeros(c, device=out.device, dtype=torch.float32)
+    dot = scratch.zeros((b, c), out.device)
     rc = _lib.load().ideas_act_bwd_dot(_lib.ptr(gpre), _lib.ptr(bg), _lib.ptr(dot), _lib.ptr(gy), _lib.ptr(out),
                                        _lib.ptr(bias), None, b, h * w, c, float(alpha), float(act_gain), _lib.act_dtype(out),
                                        _lib.stream_ptr())
     _lib.check(rc, "ideas_act_bwd_dot")
-    return gpre, bg, dot
+    return gpre, (None if bias_grad_into is not None else bg), dot
 
 
 class _ModConvAct(Function):
@@ -146,11 +148,13 @@ class _ModConvAct(Function):
     @staticmethod
     def forward(ctx, x, w, s, d, b, gain: float, slope: float, act_gain: float):
         x = _nhwc(x)
+        bias_param = b
         s, d, b = s.contiguous(), d.contiguous(), b.contiguous()
         k = w.shape[2]
         g = ConvGeom(k, k, 1, k // 2, False)
         y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d, bias=b, act=True, act_gain=act_gain, alpha=slope)
         ctx.g, ctx.gain, ctx.slope, ctx.act_gain = g, gain, slope, act_gain
+        ctx.bias_ref = bias_param
         ctx.save_for_backward(x, w, s, d, b, y)
         return y
 
@@ -160,7 +164,8 @@ class _ModConvAct(Function):
         x, w, s, d, b, y = ctx.saved_tensors
         g, gain = ctx.g, ctx.gain
         need_x, need_w, need_s, need_d, need_b = ctx.needs_input_grad[:5]
-        gpre, gb, dot = act_bwd_dot(gy, y, b, ctx.slope, ctx.act_gain)
+        from .fused_act import bias_sink
+        gpre, gb, dot = act_bwd_dot(gy, y, b, ctx.slope, ctx.act_gain, bias_grad_into=bias_sink(ctx.bias_ref) if need_b else None)
         gx = gw = gs = gd = None
         if need_x or need_s:
             gx = conv_dgrad_raw(gpre, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
@@ -172,7 +177,7 @@ class _ModConvAct(Function):
             gs = torch.where(s != 0, ds / s, torch.zeros_like(ds))
         if need_d:
             gd = dot / d
-        return (gx if need_x else None), gw, gs, gd, (gb if need_b else None), None, None, None
+        return (gx if need_x else None), gw, gs, gd, (gb if need_b else None), None, None, None     # gb is None when sunk
 
 
 _SECOND_ORDER = [False]

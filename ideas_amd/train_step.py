@@ -30,7 +30,7 @@ import torch
 from torch import optim
 from torch.nn import functional as F
 
-from .op import conv_plan
+from .op import conv_plan, scratch
 from .op.conv import grad_sink
 from .utils import (Box, accumulate, d_logistic_loss, d_r1_loss, draw_boxes, g_nonsaturating_loss,
                     message_to_tensor, patchify_image, requires_grad, tensor_to_message)
@@ -139,9 +139,11 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
                     reducer=None, hook: Optional[Callable] = None) -> Dict[str, torch.Tensor]:
     """``_train_iteration`` with the derived-weight cache (op/conv_plan.py) switched on for its duration."""
     conv_plan.cache_begin()
+    scratch.begin(X.device)          # one pre-zeroed arena (one memset) for the small reduction outputs of the backward passes
     try:
         return _train_iteration(trainer, args, X, iter_idx, draws, reducer, hook)
     finally:
+        scratch.end()
         conv_plan.cache_end()
 
 

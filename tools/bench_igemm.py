@@ -54,8 +54,22 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: same work, lower power)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="activation dtype (bf16: csrc/conv_bf16.hip)")
+    ap.add_argument("--cfg", type=int, default=-1, help="bf16 forward-family tile shape A/B (ideas_tune_bf16_fwd in csrc/conv_bf16.hip)")
     a = ap.parse_args()
     adt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if a.cfg >= 0:
+        import ctypes as C
+        from ideas_amd import _lib
+        lib = _lib.load()
+        tune, orig = lib.ideas_tune_bf16_fwd, lib.ideas_conv_igemm
+        P = C.c_void_p
+        tune.restype, tune.argtypes = C.c_int, [C.c_int, P, P, P, C.c_int, P, P, P, C.POINTER(_lib.ConvParams), P]
+
+        def patched(y, x, w, ins, outs, bias, resid, p, dtype, stream):
+            if dtype == _lib.BF16:
+                return tune(a.cfg, y, x, w, int(ins is not None), outs, bias, resid, p, stream)
+            return orig(y, x, w, ins, outs, bias, resid, p, dtype, stream)
+        lib.ideas_conv_igemm = patched
     dev = torch.device("cuda")
     tot_f = tot_t = 0.0
     from ideas_amd.op import conv_plan
