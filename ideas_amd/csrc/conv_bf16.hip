@@ -648,6 +648,12 @@ extern "C" int ideas_bf16_pack_weights(void* pack, const void* wmat, const float
 // called by ideas_conv_igemm / ideas_conv_wgrad for dtype IDEAS_BF16 once the arguments are validated
 int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                    const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    // Measured (tools/bench_igemm.py --dtype bf16 --cfg N, profiles/r02_bf16_tile_sweep.txt): with >= 256 output channels the
+    // 8-wave 256 x 128 tile is 8-10 % ahead of the 4-wave 128 x 128 tile (0.375 instead of 0.5 DMA pieces per MFMA), 256 x 256 adds
+    // 1-3 % on 512-channel layers only and loses badly below; a fourth LDS stage and a register-prefetch pipeline (fragments of
+    // tile t+1 read under the MFMAs of tile t) both measured 3-5 % SLOWER than three stages + counted vmcnt.
+    const int64_t rows = (int64_t)(per_image ? 1 : p->B) * p->OH * p->OW;
+    if (p->Cout >= 256 && rows >= 256) return launch_bf16_cfg<4, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256 x 128, 8 waves
     if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 128
     if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 64
     return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);                     // 128 x 32
@@ -663,7 +669,7 @@ extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* 
         case 2: return launch_bf16_cfg<2, 2, 4, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x128, 4 waves
         case 3: return launch_bf16_cfg<4, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x128, 8 waves
         case 4: return launch_bf16_cfg<2, 4, 4, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x256, 8 waves
-        case 5: return launch_bf16_cfg<2, 2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 2 stages
+        case 5: return launch_bf16_cfg<2, 2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 2 stages (vmcnt(0) every step)
         case 6: return launch_bf16_cfg<2, 2, 2, 4, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128x256, 4 waves
         default: return IDEAS_E_UNSUPPORTED;
     }
