@@ -194,8 +194,8 @@ def _pmc_traffic(kernel_substr: str, prefix: str):
         return None, None
 
 
-def _cpu_baseline_worker(R: int, threads: int):
-    """Runs in a child process: one oracle iteration (D phase + G/Ex phase with backward) at batch 1."""
+def _cpu_baseline_worker(R: int, threads: int, B: int = 1):
+    """Runs in a child process: one oracle iteration (D phase + G/Ex phase with backward) at batch B."""
     import oracle.torch_ref as O
     from ideas_amd.models import init_model
     from ideas_amd import train_step as TS
@@ -212,11 +212,11 @@ def _cpu_baseline_worker(R: int, threads: int):
                    for k, v in m.state_dict().items()}
     cfg = O.Cfg(image_size=R)
     sargs = O.StepArgs(use_dco=big)
-    X = torch.rand(1, 3, R, R) * 2 - 1
+    X = torch.rand(B, 3, R, R) * 2 - 1
     random.seed(0)
     s = R // 16
-    dr = O.StepDraws(Z_d=torch.rand(1, 1, s, s) * 2 - 1, T2_d=torch.rand(1, 2048) * 2 - 1,
-                     Z_g=torch.rand(1, 1, s, s) * 2 - 1, T2_g=torch.rand(1, 2048) * 2 - 1)
+    dr = O.StepDraws(Z_d=torch.rand(B, 1, s, s) * 2 - 1, T2_d=torch.rand(B, 2048) * 2 - 1,
+                     Z_g=torch.rand(B, 1, s, s) * 2 - 1, T2_g=torch.rand(B, 2048) * 2 - 1)
     if big:
         dr.boxes_d_fake, dr.boxes_d_real = O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 8)
         dr.boxes_d_ref, dr.boxes_g_fake, dr.boxes_g_ref = O.draw_boxes(R, R, 32), O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 32)
@@ -254,9 +254,28 @@ def cpu_baseline():
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "timed out"}
 
 
+def cpu_baseline_config1():
+    """BASELINE.json configs[0] beside it: 64x64, batch 4, the Dco-less sub-step (the reference's Dco cannot run below 256x256,
+    models.py:400), one iteration forward + backward on the host cores."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 64)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "64", str(threads), "4"],
+                           capture_output=True, text=True, timeout=150, cwd=ROOT)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            d = json.loads(line[-1])
+            return {"value": round(4.0 / d["seconds"], 4), "unit": "images/sec", "cores": d["threads"], "kind": "port",
+                    "sample": "1 iteration (D phase + G/Ex phase fwd+bwd, Dco-less sub-step, no R1, no optimiser), batch 4, 64x64, "
+                              "full width; %.1f s" % d["seconds"]}
+    except subprocess.TimeoutExpired:
+        pass
+    return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "timed out"}
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]))
+        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
         return
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -269,6 +288,18 @@ def main():
     # IDEAS_BENCH_SHARE_GPU=1 (+ IDEAS_DIST_BACKEND=gloo) lets the multi-rank code path be exercised on a 1-GPU box
     if os.environ.get("IDEAS_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    if world > 1:
+        # one process per GPU on a shared host: give every rank its own slice of the host cores (the step issues ~5000 small
+        # launches per iteration from Python; ranks competing for the same cores would serialise them)
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // world)
+            mine = cores[int(os.environ.get("LOCAL_RANK", "0")) * per:(int(os.environ.get("LOCAL_RANK", "0")) + 1) * per]
+            if mine:
+                os.sched_setaffinity(0, mine)
+                torch.set_num_threads(max(1, min(8, len(mine))))
+        except (AttributeError, OSError):
+            pass
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -350,13 +381,17 @@ def main():
         "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
                                "full-width nets, HIP kernels (BASELINE.json configs[%d])" % (a.N, a.image_size, a.image_size, a.batch, 4 if bf16 else 2),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
+                   "ranks": world, "allreduce_bytes_per_iteration": (
+                       {k: 4 * int(trainer[k].flat_g.numel()) for k in ("d_optim", "g_optim", "ex_optim") if hasattr(trainer[k], "flat_g")}
+                       if world > 1 else None),
                    "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
                    "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off",
                    "conv_arithmetic": conv_math},
         "step_gflop_per_image": round(gflop_img, 1),
         "step_tflops": round(ips / world * gflop_img / 1e3, 2),      # algorithmic f32 FLOPs of the step / time, per GPU
-        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),   # ... over the f32 MFMA peak
-        "losses": {k: round(float(v), 4) for k, v in losses.items() if v.numel() == 1},
+        # ... over the matrix peak of the arithmetic: f32 MFMA (157.3) for the f32 line, dense bf16 MFMA (2500) for the bf16 line
+        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS), 4),
+        "losses": {k: round(float(v.detach()), 4) for k, v in losses.items() if v.numel() == 1},
     }
     if a.roofline == "on":
         del trainer
@@ -364,6 +399,7 @@ def main():
         out["roofline"] = probe(device, a.batch, a.roofline_launches)
     if a.cpu_baseline == "auto" and world == 1:
         out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline_config1"] = cpu_baseline_config1()
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1,22 +1,39 @@
 #!/bin/bash
-# On the GPU box: the evidence behind bench.py's roofline object and DESIGN.md §8.
-#   tools/collect_profiles.sh <outdir under the repo>      (then copy what should be judged into profiles/)
+# On the GPU box: the evidence behind bench.py's roofline objects and DESIGN.md §8.
+#   tools/collect_profiles.sh <outdir under the repo> [f32|bf16|both]      (then copy what should be judged into profiles/)
+# Per precision: the default bench line, rocprofv3 kernel-trace stats of the roofline probe and of whole steps, and separate PMC
+# passes (no other tracing domains) on the roofline probe.  Writes <prefix>_source.json next to the PMC csvs: the hash of the
+# kernel sources that were measured, which bench.py checks before quoting `roofline.traffic` (stale passes are not reported).
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/$1
+WHAT=${2:-both}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. default bench line
-timeout 600 python $R/bench.py > $OUT/bench_default.log 2>&1
-tail -1 $OUT/bench_default.log > $OUT/bench_default.json
-# 2. kernel-trace stats of the roofline probe and of whole steps
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/roofline -- python $R/bench.py --roofline only > $OUT/roofline.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -- python $R/bench.py --steps 3 --warmup 1 --cpu-baseline skip --roofline off > $OUT/step.log 2>&1
-# 3. PMC passes on the roofline probe (separate passes, no other tracing domains)
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
-         "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" \
-         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"; do
-  tag=$(echo $C | cut -d' ' -f1 | tr 'A-Z' 'a-z')
-  timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python $R/bench.py --roofline only --roofline-launches 6 > $OUT/pmc_$tag.log 2>&1
-done
-ls -R $OUT | head -50
+sha() { python - "$@" <<'EOF'
+import hashlib, json, os, sys
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+files = sys.argv[2:]
+h = hashlib.sha256()
+for f in files:
+    h.update(open(os.path.join(root, "ideas_amd", "csrc", f), "rb").read())
+json.dump({"files": files, "sha": h.hexdigest()[:16]}, open(sys.argv[1], "w"))
+EOF
+}
+run_one() {   # $1 = precision, $2 = tag, $3.. = kernel source files
+  P=$1; T=$2; shift 2
+  timeout 900 python $R/bench.py --precision $P > $OUT/${T}_bench_default.log 2>&1
+  tail -1 $OUT/${T}_bench_default.log > $OUT/${T}_bench_default.json
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_roofline -- python $R/bench.py --precision $P --roofline only > $OUT/${T}_roofline.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_step -- python $R/bench.py --precision $P --steps 3 --warmup 1 --cpu-baseline skip --roofline off > $OUT/${T}_step.log 2>&1
+  for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+    tag=$(echo $C | cut -d' ' -f1 | tr 'A-Z' 'a-z')
+    timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${T}_pmc_$tag -- python $R/bench.py --precision $P --roofline only --roofline-launches 6 > $OUT/${T}_pmc_$tag.log 2>&1
+  done
+  sha $OUT/${T}_source.json "$@"
+}
+if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wino.hip b3.hpp common.hpp; fi
+if [ "$WHAT" = "bf16" ] || [ "$WHAT" = "both" ]; then run_one bf16 bf16 conv_bf16.hip common.hpp; fi
+ls $OUT | head -60

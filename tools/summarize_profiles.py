@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Copy what should be judged out of a tools/collect_profiles.sh output directory into profiles/ (tracked), as
+profiles/<round>_<tag>_*:  bench_default.json, roofline / step kernel_stats.csv, the PMC rows of the roofline kernel only
+(<tag>_pmc_<counter-set>.csv -> fetch_size / write_size / sq_wave / sq_insts / lds_grbm) and the source-hash sidecar.
+
+    python tools/summarize_profiles.py gpurun_out/prof_r02 r02
+"""
+import csv
+import glob
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, rnd = sys.argv[1], sys.argv[2]
+KERNEL = {"f32": "conv_b3_wino_kernel", "bf16": "conv_bf16_kernel"}
+NAMES = {"fetch_size": "fetch_size", "write_size": "write_size", "sq_wave_cycles": "sq_wave", "sq_insts_valu": "sq_insts",
+         "sq_lds_bank_conflict": "lds_grbm"}
+for tag, kern in KERNEL.items():
+    if not os.path.exists(os.path.join(src, tag + "_bench_default.json")):
+        continue
+    pre = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{'b3w' if tag == 'f32' else 'bf16'}")
+    shutil.copy(os.path.join(src, tag + "_bench_default.json"), os.path.join(ROOT, "profiles", f"{rnd}_{tag}_bench_default.json"))
+    for what in ("roofline", "step"):
+        f = glob.glob(os.path.join(src, f"{tag}_{what}", "**", "*kernel_stats.csv"), recursive=True)
+        if f:
+            shutil.copy(f[0], os.path.join(ROOT, "profiles", f"{rnd}_{tag}_{what}_kernel_stats.csv"))
+    for cset, short in NAMES.items():
+        f = glob.glob(os.path.join(src, f"{tag}_pmc_{cset}", "**", "*counter_collection.csv"), recursive=True)
+        if not f:
+            continue
+        rows = list(csv.DictReader(open(f[0])))
+        keep = [r for r in rows if kern in r["Kernel_Name"]]
+        if keep:
+            with open(pre + "_" + short + ".csv", "w", newline="") as fp:
+                w = csv.DictWriter(fp, fieldnames=list(keep[0].keys()), quoting=csv.QUOTE_ALL)
+                w.writeheader()
+                w.writerows(keep)
+    if os.path.exists(os.path.join(src, tag + "_source.json")):
+        shutil.copy(os.path.join(src, tag + "_source.json"), pre + "_source.json")
+    print(tag, "->", pre + "_*")
