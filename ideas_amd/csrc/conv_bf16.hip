@@ -340,18 +340,18 @@ __device__ __forceinline__ int chunk_slot(int r, int c) {
 }
 
 template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
-__global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restrict__ gw, const bf16_t* __restrict__ gy,
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_wgrad_kernel(float* __restrict__ gw, const bf16_t* __restrict__ gy,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ in_scale,
                                                                  const float* __restrict__ out_scale, ideas_conv_params p,
                                                                  int tiles_n, int pix_per_split, int splits_per_img,
                                                                  unsigned gy_bytes, unsigned x_bytes) {
-    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int NW = WM * WN;        // waves per block (4 or 8)
     constexpr int BM = WM * MT * 32;   // output channels of the tile
     constexpr int BN = WN * NT * 32;   // k columns of the tile
     constexpr int PIECES_G = 32 * BM * 2 / 1024, PIECES_X = 32 * BN * 2 / 1024;    // 1 KiB DMA pieces per K-step
     // every wave issues PER_G pieces of G then PER_X pieces of X per step (narrow tiles: some pieces twice) -- which operand a
     // slot belongs to is a compile-time property of the slot, so the buffer descriptor of each DMA is known to be uniform
-    constexpr int PER_G = (PIECES_G + 3) / 4, PER_X = (PIECES_X + 3) / 4;
+    constexpr int PER_G = (PIECES_G + NW - 1) / NW, PER_X = (PIECES_X + NW - 1) / NW;
     constexpr int PER = PER_G + PER_X;
     constexpr int NST = 3;                  // LDS stages (see conv_bf16_kernel: counted vmcnt, one raw barrier per step)
     constexpr int BUF = 32 * (BM + BN) * 2;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const bool is_g = j < PER_G;
-        const int q = is_g ? (wave + 4 * j) % PIECES_G : (wave + 4 * (j - PER_G)) % PIECES_X;    // piece within its operand
+        const int q = is_g ? (wave + NW * j) % PIECES_G : (wave + NW * (j - PER_G)) % PIECES_X;    // piece within its operand
         const int slot = q * 64 + lane;
         s_valid[j] = true;
         int r, c;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad_kernel(float* __restri
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const bool is_g = j < PER_G;                                   // compile-time after unrolling
-            const int q = is_g ? (wave + 4 * j) % PIECES_G : PIECES_G + (wave + 4 * (j - PER_G)) % PIECES_X;
+            const int q = is_g ? (wave + NW * j) % PIECES_G : PIECES_G + (wave + NW * (j - PER_G)) % PIECES_X;
             const int sH = is_g ? p.YH : p.IH, sW = is_g ? p.YW : p.IW, sC = is_g ? p.Cout : p.Cin;
             int iy = w_oy[j] * (is_g ? p.osy : p.sy) + s_yoff[j];
             int ix = w_ox[j] * (is_g ? p.osx : p.sx) + s_xoff[j];
@@ -577,7 +577,7 @@ int launch_bf16_wgrad_cfg(float* gw, const void* gy, const void* x, const float*
     const bool sc = in_scale && out_scale;
     const int64_t img = (int64_t)p->OH * p->OW;
     // split-K: about two waves of resident blocks (2 per CU), >= 8 steps each; modulated convs: whole splits inside one image
-    const int64_t slots = 2 * 256;
+    const int64_t slots = (WM * WN == 8 ? 1 : 2) * 256;
     int64_t splits = (2 * slots) / tiles;
     if (splits < 1) splits = 1;
     int64_t per, spi = 1;
@@ -600,7 +600,7 @@ int launch_bf16_wgrad_cfg(float* gw, const void* gy, const void* x, const float*
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
     auto go = [&](auto s_, auto rf) {
         hipLaunchKernelGGL((conv_bf16_wgrad_kernel<WM, WN, MT, NT, decltype(s_)::value, decltype(rf)::value>),
-                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const bf16_t*)gy, (const bf16_t*)x,
+                           dim3((unsigned)tiles, (unsigned)splits), dim3(64 * WM * WN), 0, stream, gw, (const bf16_t*)gy, (const bf16_t*)x,
                            in_scale, out_scale, *p, tn, (int)per, (int)spi, gy_bytes, x_bytes);
     };
     using T = std::true_type;
@@ -659,11 +659,14 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);                     // 128 x 32
 }
 
+static bool g_wgrad_wide = false;
 // Tile-shape A/B for tools/bench_igemm.py --cfg (not part of the declared ABI; the production dispatch is ideas_bf16_fwd)
 extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* wpack, int per_image, const float* out_scale,
                                    const float* bias, const void* resid, const ideas_conv_params* p, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     switch (cfg) {
+        case 100: g_wgrad_wide = false; return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
+        case 101: g_wgrad_wide = true; return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
         case 0: return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128x128, 4 waves
         case 1: return launch_bf16_cfg<2, 2, 2, 2, 4>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // + 4 stages
         case 2: return launch_bf16_cfg<2, 2, 4, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x128, 4 waves
@@ -677,6 +680,7 @@ extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* 
 
 int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                      const ideas_conv_params* p, hipStream_t stream) {
+    if (p->Cout >= 256 && g_wgrad_wide) return launch_bf16_wgrad_cfg<4, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 256 (o) x 128 (k), 8 waves
     if (p->Cout > 64) return launch_bf16_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 128 (o) x 128 (k)
     if (p->Cout > 32) return launch_bf16_wgrad_cfg<2, 2, 1, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 64 x 128
     return launch_bf16_wgrad_cfg<1, 4, 1, 1>(gw, gy, x, in_scale, out_scale, p, stream);                     // 32 x 128

@@ -67,13 +67,13 @@ class EqualConv2d(nn.Module):
             return conv2d_bias_act(input, self.weight, act.bias, stride=self.stride, padding=pad, reflect=refl,
                                    gain=self.scale, negative_slope=act.negative_slope, scale=act.scale * post_gain,
                                    resid=resid)
-        if resid is not None:
-            raise RuntimeError("resid is only supported on the fused conv + activation path")
         if act is None:
             if self.bias is not None and post_gain != 1.0:
                 raise RuntimeError("post_gain with a conv bias is not used on this path")
             return conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl,
-                          gain=self.scale * post_gain)
+                          gain=self.scale * post_gain, resid=resid)
+        if resid is not None:
+            raise RuntimeError("resid needs the fused conv + activation path or a bias-free linear conv")
         out = conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl, gain=self.scale)
         return fused_leaky_relu(out, act.bias, act.negative_slope, act.scale * post_gain)
 

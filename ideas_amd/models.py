@@ -129,11 +129,15 @@ def _res_merge(block, body, last, input):
     and — when no graph is being built — the add folded into the last conv's epilogue as well."""
     if block.skip is None:
         return (last(body(input)) + input) * _INV_SQRT2
-    skip = block.skip(input, post_gain=_INV_SQRT2)
-    h = body(input)
     if not torch.is_grad_enabled():
-        return last(h, post_gain=_INV_SQRT2, resid=skip)
-    return last(h, post_gain=_INV_SQRT2) + skip
+        skip = block.skip(input, post_gain=_INV_SQRT2)
+        return last(body(input), post_gain=_INV_SQRT2, resid=skip)
+    out = last(body(input), post_gain=_INV_SQRT2)
+    if isinstance(block.skip[-1], EqualConv2d):
+        # the skip branch ends in a bias-free linear conv (same-resolution and downsampling blocks): the merge add rides in
+        # that conv's epilogue and differentiates trivially (d/d out = the incoming gradient)
+        return block.skip(input, post_gain=_INV_SQRT2, resid=out)
+    return out + block.skip(input, post_gain=_INV_SQRT2)      # upsampling skip ends in a blur
 
 
 class StyledResBlock(nn.Module):

@@ -394,6 +394,28 @@ class _Conv(Function):
         return gx, gw, None, None
 
 
+class _ConvAdd(Function):
+    """y = gain * conv(x, w) + r with the add in the conv epilogue (the residual merge of a ResBlock: one elementwise pass
+    over the block output saved).  Same single rounding of the sum as conv -> torch.add, so bitwise the unfused result."""
+
+    @staticmethod
+    def forward(ctx, x, w, r, g: ConvGeom, gain: float):
+        ctx.g, ctx.gain = g, gain
+        x = _nhwc(x)
+        ctx.save_for_backward(x, w)
+        return conv_fwd_raw(x, w, g, gain, resid=r, resid_gain=1.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(gy, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(w, gy, x, ctx.g, ctx.gain)
+        return gx, gw, (gy if ctx.needs_input_grad[2] else None), None, None
+
+
 def _wgrad(w, gy, x, g: ConvGeom, gain: float):
     """Weight gradient of a dense conv: differentiable Function normally, sunk into w.grad inside grad_sink."""
     if _sink_target(w) is None:
@@ -445,10 +467,15 @@ class _ConvWgrad(Function):
 
 
 def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
-           padding: int = 0, reflect: bool = False, gain: float = 1.0) -> torch.Tensor:
-    """``gain * F.conv2d(input, weight, stride, padding) + bias`` (zero padding, or mirror padding if ``reflect``)."""
+           padding: int = 0, reflect: bool = False, gain: float = 1.0, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``gain * F.conv2d(input, weight, stride, padding) + bias`` (zero padding, or mirror padding if ``reflect``);
+    ``resid``: a tensor of the output's shape added in the conv epilogue (differentiable)."""
     _lib.require_cuda(input, weight, bias)
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
+    if resid is not None:
+        if bias is not None:
+            raise RuntimeError("conv2d(resid=...) with a conv bias is not used on this path")
+        return _ConvAdd.apply(to_act(input), weight, to_act(resid), g, float(gain))
     y = _Conv.apply(to_act(input), weight, g, float(gain))
     if bias is not None:
         y = y + bias.view(1, -1, 1, 1)

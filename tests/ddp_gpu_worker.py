@@ -33,6 +33,9 @@ def main():
     from ideas_amd.op import conv as CV
     from ideas_amd.optim import fuse_optimizers
     from test_nets_gpu import ZeroDco
+    from ideas_amd import precision
+    bf16 = os.environ.get("IDEAS_TEST_PRECISION", "f32") == "bf16"
+    precision.set_activation_dtype("bf16" if bf16 else "f32")     # bf16: the same branch in mixed precision (BASELINE configs[4])
 
     args = TS.default_args(channel=8, texture_channel=128, channel_multiplier=0.25, image_size=64, batch_size=2,
                            d_reg_every=2, num_iters=10)
@@ -99,7 +102,8 @@ def main():
         TS.train_iteration(ref, args, Xall, 1, draws=draws(0, slice(0, world * B)), hook=hook1)
         # 'd' precedes every optimiser step: f32 noise only.  'g' / 'ex' follow the D step, whose first Adam update is
         # lr * sign(g): noise-floor parameters may move the other way (tests/test_nets_gpu.py::check_replay), so looser.
-        for tag, tol in (("d", 1e-4), ("g", 3e-2), ("ex", 3e-2)):
+        # (bf16: per-sample arithmetic is identical in both runs, only the f32 accumulation order of the sums differs)
+        for tag, tol in (("d", 2e-3 if bf16 else 1e-4), ("g", 5e-2 if bf16 else 3e-2), ("ex", 5e-2 if bf16 else 3e-2)):
             err = float((grads[tag] - g1[tag]).abs().max() / g1[tag].abs().max())
             assert err < tol, (tag, err)
             print(f"rank-mean vs full-batch gradient [{tag}]: rel err {err:.2e}", flush=True)

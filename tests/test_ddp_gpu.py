@@ -19,8 +19,9 @@ def _free_port():
 
 
 @pytest.mark.gpu
-def test_two_ranks_share_one_gpu_through_fused_optimizers_and_reducer():
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_two_ranks_share_one_gpu_through_fused_optimizers_and_reducer(prec):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", IDEAS_TEST_PRECISION=prec)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "ddp_gpu_worker.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
