@@ -659,14 +659,11 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);                     // 128 x 32
 }
 
-static bool g_wgrad_wide = false;
 // Tile-shape A/B for tools/bench_igemm.py --cfg (not part of the declared ABI; the production dispatch is ideas_bf16_fwd)
 extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* wpack, int per_image, const float* out_scale,
                                    const float* bias, const void* resid, const ideas_conv_params* p, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     switch (cfg) {
-        case 100: g_wgrad_wide = false; return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
-        case 101: g_wgrad_wide = true; return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
         case 0: return launch_bf16_cfg<2, 2, 2, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128x128, 4 waves
         case 1: return launch_bf16_cfg<2, 2, 2, 2, 4>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // + 4 stages
         case 2: return launch_bf16_cfg<2, 2, 4, 2, 3>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256x128, 4 waves
@@ -680,7 +677,7 @@ extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* 
 
 int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                      const ideas_conv_params* p, hipStream_t stream) {
-    if (p->Cout >= 256 && g_wgrad_wide) return launch_bf16_wgrad_cfg<4, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 256 (o) x 128 (k), 8 waves
+    // (an 8-wave 256 x 128 tile, the winner of the forward family, measured 22 % SLOWER here: half the blocks for the split-K)
     if (p->Cout > 64) return launch_bf16_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 128 (o) x 128 (k)
     if (p->Cout > 32) return launch_bf16_wgrad_cfg<2, 2, 1, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 64 x 128
     return launch_bf16_wgrad_cfg<1, 4, 1, 1>(gw, gy, x, in_scale, out_scale, p, stream);                     // 32 x 128
