@@ -343,7 +343,9 @@ def main():
     from ideas_amd import precision
     precision.set_activation_dtype(a.precision)
 
-    args = TS.default_args(image_size=a.image_size, batch_size=a.batch, N=a.N,
+    # below 256x256 the reference's co-occurrence discriminator cannot run (models.py:400): the
+    # step is then the Dco-less sub-step, as in the parity fixtures (tests/golden/step_r128.npz)
+    args = TS.default_args(image_size=a.image_size, batch_size=a.batch, N=a.N, use_dco=a.image_size >= 256,
                            elide_second_backward=not a.literal_second_backward, num_iters=10 ** 9,
                            share_forward=not a.no_share_forward)
     torch.manual_seed(0)              # identical replicas on every rank (no broadcast needed)
@@ -396,11 +398,14 @@ def main():
     ips = world * a.batch * a.steps / dt
     gflop_img = flop_per_image(not a.literal_second_backward, shared=not a.no_share_forward)
     out = {
-        "metric": "train images/sec at 256x256 (G+D+Ex step)", "value": round(ips, 3), "unit": "images/sec",
+        "metric": "train images/sec at %dx%d (G+D+Ex step)" % (a.image_size, a.image_size), "value": round(ips, 3), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
-                               "full-width nets, HIP kernels (BASELINE.json configs[%d])" % (a.N, a.image_size, a.image_size, a.batch, 4 if bf16 else 2),
+                               "full-width nets, HIP kernels (BASELINE.json configs[%d]%s)"
+                               % (a.N, a.image_size, a.image_size, a.batch,
+                                  1 if a.image_size == 128 else (4 if bf16 else (3 if a.N == 2 else 2)),
+                                  "" if a.image_size >= 256 else "; Dco-less sub-step: the reference's Dco cannot run below 256x256"),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
                    "ranks": world, "allreduce_bytes_per_iteration": (
                        {k: 4 * int(trainer[k].flat_g.numel()) for k in ("d_optim", "g_optim", "ex_optim") if hasattr(trainer[k], "flat_g")}
@@ -408,10 +413,11 @@ def main():
                    "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
                    "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off",
                    "conv_arithmetic": conv_math},
-        "step_gflop_per_image": round(gflop_img, 1),
-        "step_tflops": round(ips / world * gflop_img / 1e3, 2),      # algorithmic f32 FLOPs of the step / time, per GPU
+        # (the FLOP model is the 256x256 one of SURVEY.md §8(d); other sizes report throughput only)
+        "step_gflop_per_image": round(gflop_img, 1) if a.image_size == 256 else None,
+        "step_tflops": round(ips / world * gflop_img / 1e3, 2) if a.image_size == 256 else None,   # algorithmic FLOPs of the step / time, per GPU
         # ... over the matrix peak of the arithmetic: f32 MFMA (157.3) for the f32 line, dense bf16 MFMA (2500) for the bf16 line
-        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS), 4),
+        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS), 4) if a.image_size == 256 else None,
         "losses": {k: round(float(v.detach()), 4) for k, v in losses.items() if v.numel() == 1},
     }
     out["vs_rocm_eager"] = vs_rocm_eager(ips, a, world)
