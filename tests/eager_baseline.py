@@ -24,9 +24,41 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-benchmark", action="store_true", help="cudnn.benchmark off: MIOpen immediate mode, no per-shape find")
+    ap.add_argument("--stub-convs", action="store_true",
+                    help="replace every F.conv2d / F.conv_transpose2d (forward and both gradients) by an allocation of the right shape: "
+                         "times everything ELSE the eager step runs (bias/act, residual merges, demodulation, per-sample weight "
+                         "materialisation, patch resampling, losses, Adam) without touching MIOpen; with the measured convolution time "
+                         "of tools/eager_partial.py the sum is a lower bound of the eager iteration (one stream, kernels run back to back)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     torch.backends.cudnn.benchmark = not a.no_benchmark     # the reference sets True (train.py:327)
+    if a.stub_convs:
+        import torch.nn.functional as F
+
+        class _Stub(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w, shape):
+                ctx.save_for_backward(x, w)
+                return torch.empty(shape, device=x.device, dtype=x.dtype)
+
+            @staticmethod
+            def backward(ctx, gy):
+                x, w = ctx.saved_tensors
+                return (torch.empty_like(x) if ctx.needs_input_grad[0] else None,
+                        torch.empty_like(w) if ctx.needs_input_grad[1] else None, None)
+
+        def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
+            oh = (x.shape[2] + 2 * padding - w.shape[2]) // stride + 1
+            ow = (x.shape[3] + 2 * padding - w.shape[3]) // stride + 1
+            y = _Stub.apply(x, w, (x.shape[0], w.shape[0], oh, ow))
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+        def conv_transpose2d(x, w, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+            oh = (x.shape[2] - 1) * stride - 2 * padding + w.shape[2]
+            ow = (x.shape[3] - 1) * stride - 2 * padding + w.shape[3]
+            y = _Stub.apply(x, w, (x.shape[0], w.shape[1] * groups, oh, ow))
+            return y if bias is None else y + bias.view(1, -1, 1, 1)
+        F.conv2d, F.conv_transpose2d = conv2d, conv_transpose2d
     R = 256
     args = TS.default_args(image_size=R)
     torch.manual_seed(0)
@@ -90,6 +122,7 @@ def main():
     dt = time.perf_counter() - t0
     print(json.dumps({"eager_gpu_images_per_sec": round(B * a.steps / dt, 3), "ms_per_step": round(dt / a.steps * 1e3, 1),
                       "batch": B, "steps": a.steps, "cudnn_benchmark": not a.no_benchmark, "warmup_s": round(t_w, 1), "channels_last": a.channels_last,
+                      "convs": "stubbed (allocation only)" if a.stub_convs else "MIOpen",
                       "note": "oracle step (no R1, elided 2nd backward, no EMA) on cuda:0, MIOpen convs, torch %s" % torch.__version__,
                       "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
 
