@@ -58,16 +58,21 @@ _PROTOS = {
     "ideas_b3_wino_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wino_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P]),
     "ideas_b3_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_b3_split_weights_strided": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [_P]),
     "ideas_bf16_conv_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int]),
     "ideas_bf16_wgrad_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int]),
     "ideas_bf16_direct_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_bf16_pack_weights": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_bf16_pack_weights_strided": (C.c_int, [_P, _P, _P] + [C.c_int] * 5 + [C.c_int64] * 4 + [_P]),
     "ideas_conv3x3_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv3x3_wino_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv_direct": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv_wgrad_direct": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_demod": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "ideas_weight_sqsum": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_float, _P]),
+    "ideas_demod_bwd": (C.c_int, [_P] * 7 + [C.c_int] * 3 + [_P]),
+    "ideas_demod_wgrad": (C.c_int, [_P] * 4 + [C.c_int] * 5 + [C.c_int64] * 8 + [C.c_float, _P]),
     "ideas_pixel_dot": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
     "ideas_reflect_fold": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_adam_ema": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),

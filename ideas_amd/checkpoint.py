@@ -38,6 +38,10 @@ def load(path: str, trainer: Dict[str, object], map_location="cpu") -> int:
 
 
 def _restore_weight_layout(module: torch.nn.Module) -> None:
+    from .model import ModulatedConv2d, modconv_weight_layout
     for p in module.parameters():
         if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
             p.data = p.data.contiguous(memory_format=torch.channels_last)
+    for m in module.modules():
+        if isinstance(m, ModulatedConv2d):
+            m.weight.data = modconv_weight_layout(m.weight.data, m.upsample)

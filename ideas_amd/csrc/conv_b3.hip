@@ -55,6 +55,37 @@ __global__ __launch_bounds__(256) void split_weights_kernel(uint2* __restrict__ 
     }
 }
 
+// The same planes read straight from the parameter: element (n, ty, tx, ci) of the launch's matrix at
+// w[n*sn + ty*sty + tx*stx + ci*sc] (see ideas_bf16_pack_weights_strided, conv_bf16.hip).
+template <bool UNIT>
+__global__ __launch_bounds__(256) void split_weights_strided_kernel(uint2* __restrict__ dst, const float* __restrict__ w, int Cout,
+                                                                    int TY, int TX, int Cin, int64_t sn, int64_t sty, int64_t stx,
+                                                                    int64_t sc) {
+    const int c4 = Cin / 4, ntaps = TY * TX;
+    const int64_t n4 = (int64_t)Cout * ntaps * c4;
+    const int64_t plane = n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        int n, tap, ci;
+        if (UNIT) {
+            ci = (int)(i % c4) * 4;
+            tap = (int)((i / c4) % ntaps);
+            n = (int)(i / ((int64_t)c4 * ntaps));
+        } else {
+            n = (int)(i % Cout);
+            ci = (int)((i / Cout) % c4) * 4;
+            tap = (int)(i / ((int64_t)Cout * c4));
+        }
+        const int ty = tap / TX, tx = tap - ty * TX;
+        const float* src = w + n * sn + ty * sty + tx * stx + ci * sc;
+        const float4 v = UNIT ? *reinterpret_cast<const float4*>(src) : make_float4(src[0], src[sc], src[2 * sc], src[3 * sc]);
+        const int step = (ci >> 4) * ntaps + tap;
+        const Split4 s = split4(v);
+        const int64_t o = ((int64_t)step * Cout + n) * 4 + ((ci & 15) >> 2);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl * plane + o] = s.p[pl];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward family
 // ---------------------------------------------------------------------------------------------------------------
@@ -340,5 +371,22 @@ extern "C" int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, 
     const int blocks = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
     hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint2*)planes,
                        (const float4*)wmat, Cout, K, Cin);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_b3_split_weights_strided(void* planes, const float* w, int Cout, int TY, int TX, int Cin, int64_t sn, int64_t sty,
+                                              int64_t stx, int64_t sc, void* stream_) {
+    if (!planes || !w) return IDEAS_E_NULL;
+    if (Cout <= 0 || TY <= 0 || TX <= 0 || Cin <= 0) return IDEAS_E_SHAPE;
+    if (Cin % 16 || !ideas_aligned16(planes)) return IDEAS_E_ALIGN;
+    const int64_t n4 = (int64_t)Cout * TY * TX * (Cin / 4);
+    const int blocks = (int)(n4 / 256 + 1 < 2048 ? n4 / 256 + 1 : 2048);
+    const bool unit = sc == 1 && ideas_aligned16(w) && sn % 4 == 0 && sty % 4 == 0 && stx % 4 == 0;
+    if (unit)
+        hipLaunchKernelGGL(split_weights_strided_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint2*)planes, w, Cout,
+                           TY, TX, Cin, sn, sty, stx, sc);
+    else
+        hipLaunchKernelGGL(split_weights_strided_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (uint2*)planes, w, Cout,
+                           TY, TX, Cin, sn, sty, stx, sc);
     return ideas_launch_status();
 }

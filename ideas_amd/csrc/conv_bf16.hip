@@ -85,6 +85,53 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(uint4* __restrict__ d
     }
 }
 
+// The same pack read straight from the PARAMETER: element (n, ty, tx, ci) of the launch's weight matrix lies at
+// w[n*sn + ty*sty + tx*stx + ci*sc] (f32 elements) -- the forward matrix of an [O,I,KH,KW] tensor of any strides, the
+// phase-sliced transposed matrix of an input gradient, or the matrix of a transposed conv -- so no permuted / sliced f32 copy is
+// materialised first (one launch instead of copy + pack, and 2-4 launches fewer per conv and step than torch's slicing).
+template <bool UNIT>
+__global__ __launch_bounds__(256) void pack_weights_strided_kernel(uint4* __restrict__ dst, const float* __restrict__ w,
+                                                                   const float* __restrict__ scale, int Cout, int TY, int TX, int Cin,
+                                                                   int64_t sn, int64_t sty, int64_t stx, int64_t sc) {
+    const int c8 = Cin / 8, ntaps = TY * TX;
+    const int64_t n8 = (int64_t)Cout * ntaps * c8;
+    const int b = blockIdx.y;
+    const float* sb = scale ? scale + (int64_t)b * Cin : nullptr;
+    uint4* out = dst + (int64_t)b * n8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        // UNIT (sc == 1): consecutive threads read consecutive 32-byte pieces of one (n, tap) row; otherwise consecutive
+        // threads take consecutive n (the contiguous index of a transposed read) of one (tap, 8-channel chunk)
+        int n, tap, ci;
+        if (UNIT) {
+            ci = (int)(i % c8) * 8;
+            tap = (int)((i / c8) % ntaps);
+            n = (int)(i / ((int64_t)c8 * ntaps));
+        } else {
+            n = (int)(i % Cout);
+            ci = (int)((i / Cout) % c8) * 8;
+            tap = (int)(i / ((int64_t)Cout * c8));
+        }
+        const int ty = tap / TX, tx = tap - ty * TX;
+        const float* src = w + n * sn + ty * sty + tx * stx + ci * sc;
+        float v[8];
+        if (UNIT) {
+            const float4 u0 = *reinterpret_cast<const float4*>(src), u1 = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[j * sc];
+        }
+        if (sb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= sb[ci + j];
+        }
+        const int step = (ci >> 5) * ntaps + tap;
+        const int c = (ci & 31) >> 3;
+        out[((int64_t)step * Cout + n) * 4 + (c ^ ((n >> 2) & 3))] =
+            make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward family
 // ---------------------------------------------------------------------------------------------------------------
@@ -642,6 +689,25 @@ extern "C" int ideas_bf16_pack_weights(void* pack, const void* wmat, const float
     const int blocks = (int)(n8 / 256 + 1 < 2048 ? n8 / 256 + 1 : 2048);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, in_scale ? B : 1), dim3(256), 0, (hipStream_t)stream_, (uint4*)pack,
                        (const float4*)wmat, in_scale, Cout, K, Cin);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_bf16_pack_weights_strided(void* pack, const float* w, const float* in_scale, int B, int Cout, int TY, int TX,
+                                               int Cin, int64_t sn, int64_t sty, int64_t stx, int64_t sc, void* stream_) {
+    if (!pack || !w) return IDEAS_E_NULL;
+    if (Cout <= 0 || TY <= 0 || TX <= 0 || Cin <= 0 || B <= 0 || B > 65535) return IDEAS_E_SHAPE;
+    if (Cin % 32 || !ideas_aligned16(pack) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
+    if (!in_scale && B != 1) return IDEAS_E_SHAPE;
+    const int64_t n8 = (int64_t)Cout * TY * TX * (Cin / 8);
+    const int blocks = (int)(n8 / 256 + 1 < 2048 ? n8 / 256 + 1 : 2048);
+    const bool unit = sc == 1 && ideas_aligned16(w) && sn % 4 == 0 && sty % 4 == 0 && stx % 4 == 0;
+    const dim3 grid(blocks, in_scale ? B : 1);
+    if (unit)
+        hipLaunchKernelGGL(pack_weights_strided_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream_, (uint4*)pack, w, in_scale, Cout,
+                           TY, TX, Cin, sn, sty, stx, sc);
+    else
+        hipLaunchKernelGGL(pack_weights_strided_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream_, (uint4*)pack, w, in_scale, Cout,
+                           TY, TX, Cin, sn, sty, stx, sc);
     return ideas_launch_status();
 }
 

@@ -24,6 +24,74 @@ __global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const
     if (lane == 0) d[idx] = rsqrtf(acc + eps);
 }
 
+// wsq[o][i] = scale2 * sum_k W[o][i][k]^2 of a 4-D weight of any strides (one thread per (o, i); the fastest-varying thread
+// index follows the smaller of the two channel strides so the reads coalesce in either memory format).
+__global__ __launch_bounds__(256) void weight_sqsum_kernel(float* __restrict__ wsq, const float* __restrict__ w, int Cout, int Cin,
+                                                           int KH, int KW, int64_t so, int64_t si, int64_t sky, int64_t skx,
+                                                           float scale2) {
+    const int64_t n = (int64_t)Cout * Cin;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int o, i;
+    if (so < si) { o = (int)(t % Cout); i = (int)(t / Cout); } else { i = (int)(t % Cin); o = (int)(t / Cin); }
+    const float* p = w + o * so + i * si;
+    float acc = 0.f;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) { const float v = p[ky * sky + kx * skx]; acc = fmaf(v, v, acc); }
+    wsq[(int64_t)o * Cin + i] = acc * scale2;
+}
+
+// Backward of the demodulation folded into the style gradient.  Inputs: the two per-sample reductions of the conv backward,
+//   dot_s[b,i] = <x, gx>[b,i]  (gx = s * dL/d(s x))        dot_d[b,o] = <gy, y>[b,o]  (y = d * conv)
+// Outputs: gq[b,o] = dL/dq of d = (q + eps)^(-1/2), q[b,o] = sum_i s^2 wsq:  gq = -0.5 * (dot_d / d) * d^3 = -0.5 * dot_d * d^2,
+//          gs[b,i] = (s != 0 ? dot_s / s : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (d, dot_d == NULL: first term only).
+// Grid (ceil(Cin / 256), B); every block recomputes gq[b, :] into LDS (Cout values) and block x == 0 also stores it.
+__global__ __launch_bounds__(256) void demod_bwd_kernel(float* __restrict__ gs, float* __restrict__ gq, const float* __restrict__ dot_s,
+                                                        const float* __restrict__ dot_d, const float* __restrict__ d,
+                                                        const float* __restrict__ s, const float* __restrict__ wsq, int Cin, int Cout) {
+    extern __shared__ float s_gq[];
+    const int b = blockIdx.y;
+    if (d) {
+        for (int o = threadIdx.x; o < Cout; o += 256) {
+            const float dv = d[(int64_t)b * Cout + o];
+            const float q = -0.5f * dot_d[(int64_t)b * Cout + o] * dv * dv;
+            s_gq[o] = q;
+            if (blockIdx.x == 0) gq[(int64_t)b * Cout + o] = q;
+        }
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cin) return;
+    const float sv = s[(int64_t)b * Cin + i];
+    float g = sv != 0.f ? dot_s[(int64_t)b * Cin + i] / sv : 0.f;
+    if (d) {
+        float acc = 0.f;
+        for (int o = 0; o < Cout; ++o) acc = fmaf(s_gq[o], wsq[(int64_t)o * Cin + i], acc);
+        g = fmaf(2.f * sv, acc, g);
+    }
+    gs[(int64_t)b * Cin + i] = g;
+}
+
+// Weight gradient through the demodulation:  gw[o][i][k] += coef * W[o][i][k] * sum_b gq[b,o] * s[b,i]^2   (coef = 2 scale^2),
+// added in place to a gradient tensor of strides (go, gi, gky, gkx) -- the parameter's .grad or a fresh buffer.
+__global__ __launch_bounds__(256) void demod_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ w, const float* __restrict__ gq,
+                                                          const float* __restrict__ s, int B, int Cout, int Cin, int KH, int KW,
+                                                          int64_t so, int64_t si, int64_t sky, int64_t skx, int64_t go, int64_t gi,
+                                                          int64_t gky, int64_t gkx, float coef) {
+    const int64_t n = (int64_t)Cout * Cin;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int o, i;
+    if (so < si) { o = (int)(t % Cout); i = (int)(t / Cout); } else { i = (int)(t % Cin); o = (int)(t / Cin); }
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) { const float sv = s[(int64_t)b * Cin + i]; acc = fmaf(gq[(int64_t)b * Cout + o], sv * sv, acc); }
+    acc *= coef;
+    const float* wp = w + o * so + i * si;
+    float* gp = gw + o * go + i * gi;
+    for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) gp[ky * gky + kx * gkx] = fmaf(acc, wp[ky * sky + kx * skx], gp[ky * gky + kx * gkx]);
+}
+
 template <typename T, typename V>      // T = element (float / bf16), V = four consecutive elements
 __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out, const T* __restrict__ a,
                                                         const T* __restrict__ g, int64_t P, int C,
@@ -137,6 +205,37 @@ extern "C" int ideas_demod(float* d, const float* s, const float* wsq, int B, in
     const int64_t waves = (int64_t)B * Cout;
     hipLaunchKernelGGL(demod_kernel, dim3((unsigned)ideas_cdiv(waves, 4)), dim3(256), 0, (hipStream_t)stream, d, s, wsq,
                        B, Cin, Cout, eps);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_weight_sqsum(float* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky,
+                                  int64_t skx, float scale2, void* stream) {
+    if (!wsq || !w) return IDEAS_E_NULL;
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return IDEAS_E_SHAPE;
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(weight_sqsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsq, w, Cout, Cin, KH,
+                       KW, so, si, sky, skx, scale2);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_demod_bwd(float* gs, float* gq, const float* dot_s, const float* dot_d, const float* d, const float* s,
+                               const float* wsq, int B, int Cin, int Cout, void* stream) {
+    if (!gs || !dot_s || !s) return IDEAS_E_NULL;
+    if (d && (!gq || !dot_d || !wsq)) return IDEAS_E_NULL;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535 || Cout > 16384) return IDEAS_E_SHAPE;
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Cin + 255) / 256, B), dim3(256), d ? Cout * sizeof(float) : 0, (hipStream_t)stream, gs, gq,
+                       dot_s, dot_d, d, s, wsq, Cin, Cout);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_demod_wgrad(float* gw, const float* w, const float* gq, const float* s, int B, int Cout, int Cin, int KH, int KW,
+                                 int64_t so, int64_t si, int64_t sky, int64_t skx, int64_t go, int64_t gi, int64_t gky, int64_t gkx,
+                                 float coef, void* stream) {
+    if (!gw || !w || !gq || !s) return IDEAS_E_NULL;
+    if (B <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return IDEAS_E_SHAPE;
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(demod_wgrad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gw, w, gq, s, B, Cout,
+                       Cin, KH, KW, so, si, sky, skx, go, gi, gky, gkx, coef);
     return ideas_launch_status();
 }
 

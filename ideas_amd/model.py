@@ -17,6 +17,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .op.linear import equal_linear
 from .op import FusedLeakyReLU, conv2d, conv2d_bias_act, fused_leaky_relu, modulated_conv2d, upfirdn2d
 
 CL = torch.channels_last
@@ -94,13 +95,13 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
-        # (x * scale) @ W^T instead of x @ (W * scale)^T (stylegan2/model.py:152-160): the same product re-associated, with
-        # the [B, in] activation scaled instead of the [out, in] weight (and no scaled-weight pass in the backward either)
-        x = (input if input.dtype == torch.float32 else input.float()) * self.scale       # linear layers are f32 in every mode
+        # scale * (x @ W^T) instead of x @ (W * scale)^T (stylegan2/model.py:152-160): the same product with the equalised-lr scale
+        # in the GEMM's alpha — no scaled copy of the [out, in] weight, forward or backward (op/linear.py)
+        x = input if input.dtype == torch.float32 else input.float()       # linear layers are f32 in every mode
         b = self.bias if (self.bias is None or self.lr_mul == 1) else self.bias * self.lr_mul
         if self.activation:
-            return fused_leaky_relu(F.linear(x, self.weight), b)
-        return F.linear(x, self.weight, bias=b)
+            return fused_leaky_relu(equal_linear(x, self.weight, None, self.scale), b)
+        return equal_linear(x, self.weight, b, self.scale)
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
@@ -115,6 +116,16 @@ class ScaledLeakyReLU(nn.Module):
 
     def forward(self, input):
         return fused_leaky_relu(input, None, self.negative_slope, math.sqrt(2))
+
+
+def modconv_weight_layout(w5: torch.Tensor, upsample: bool) -> torch.Tensor:
+    """The [1, O, I, k, k] parameter of the reference (stylegan2/model.py:225-227) in the memory order the kernels read and
+    accumulate without a copy: (o, ky, kx, i) for the same-resolution conv, (i, ky, kx, o) for the transposed (upsample) one —
+    i.e. the conv weight [O, I] resp. its transposed-conv reading [I, O] is channels_last.  Shape and values are unchanged
+    (state_dict / load_state_dict are layout-agnostic)."""
+    w = w5[0].transpose(0, 1) if upsample else w5[0]
+    w = w.contiguous(memory_format=CL)
+    return (w.transpose(0, 1) if upsample else w).unsqueeze(0)
 
 
 class ModulatedConv2d(nn.Module):
@@ -135,7 +146,7 @@ class ModulatedConv2d(nn.Module):
             self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
         self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
         self.padding = kernel_size // 2
-        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.weight = nn.Parameter(modconv_weight_layout(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size), upsample))
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
 

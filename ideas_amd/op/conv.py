@@ -93,21 +93,36 @@ def _f32(t):
     return None if t is None else t.float()
 
 
-def bf16_pack(L: Launch, w: torch.Tensor, in_scale=None) -> torch.Tensor:
-    """bf16 pack of a forward-family weight matrix for ideas_conv_igemm(IDEAS_BF16).  Plain convs: one pack, memoised like
-    the b3 planes.  Modulated convs (in_scale [B, Cin]): one pack per sample, w * in_scale[b] — never cached (it depends on
-    the styles) and freed after the launch."""
-    k = L.TY * L.TX * L.Cin
+def bf16_pack(L: Launch, in_scale=None) -> torch.Tensor:
+    """bf16 pack of a forward-family weight matrix for ideas_conv_igemm(IDEAS_BF16), read from the parameter through the strides
+    of ``L.wview``.  Plain convs: one pack, memoised like the b3 planes.  Modulated convs (in_scale [B, Cin]): one pack per
+    sample, w * in_scale[b] — never cached (it depends on the styles) and freed after the launch."""
+    v = L.wview
     nb = 1 if in_scale is None else L.B
 
     def make():
-        pk = torch.empty(nb * L.Cout * k, device=w.device, dtype=BF)
-        _lib.check(_lib.load().ideas_bf16_pack_weights(_lib.ptr(pk), _lib.ptr(w), _lib.ptr(in_scale), nb, L.Cout, k, L.Cin,
-                                                        _lib.stream_ptr()), "ideas_bf16_pack_weights")
+        pk = torch.empty(nb * L.Cout * L.TY * L.TX * L.Cin, device=v.device, dtype=BF)
+        sn, sty, stx, sc = v.stride()
+        _lib.check(_lib.load().ideas_bf16_pack_weights_strided(_lib.ptr(pk), _lib.ptr(v), _lib.ptr(in_scale), nb, L.Cout, L.TY, L.TX,
+                                                                L.Cin, sn, sty, stx, sc, _lib.stream_ptr()),
+                   "ideas_bf16_pack_weights_strided")
         return pk
     if in_scale is not None or L.wsrc is None:
         return make()
     return conv_plan.cached(L.wsrc, ("bf16",) + L.wkey, make)
+
+
+def b3_planes(L: Launch) -> torch.Tensor:
+    """Split-bf16 planes of a forward-family weight matrix for ideas_conv_igemm(IDEAS_F32_B3), memoised per optimiser step."""
+    v = L.wview
+
+    def split():
+        pl = torch.empty(3 * L.Cout * L.TY * L.TX * L.Cin, device=v.device, dtype=BF)
+        sn, sty, stx, sc = v.stride()
+        _lib.check(_lib.load().ideas_b3_split_weights_strided(_lib.ptr(pl), _lib.ptr(v), L.Cout, L.TY, L.TX, L.Cin, sn, sty, stx, sc,
+                                                               _lib.stream_ptr()), "ideas_b3_split_weights_strided")
+        return pl
+    return conv_plan.cached(L.wsrc, ("b3",) + L.wkey, split) if L.wsrc is not None else split()
 
 
 def _params(L: Launch, gain: float, accumulate: bool = False, act: bool = False, alpha: float = 0.2,
@@ -123,17 +138,14 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
     """Enqueue one forward-family launch (MFMA implicit GEMM when Cin % 4 == 0, VALU direct otherwise)."""
     lib = _lib.load()
     p = _params(L, gain, accumulate, act, alpha, act_gain, resid_gain)
-    w = L.wmat
-    if not w.is_contiguous():
-        w = w.contiguous()
     if x.dtype == BF:
         if lib.ideas_bf16_conv_supported(C.byref(p), int(in_scale is not None)):
-            rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bf16_pack(L, w, in_scale)), _lib.ptr(in_scale), _lib.ptr(out_scale),
+            rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(bf16_pack(L, in_scale)), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                       _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.BF16, _lib.stream_ptr())
             _lib.check(rc, "ideas_conv_igemm[bf16]")
             return
         if lib.ideas_bf16_direct_supported(C.byref(p)) and in_scale is None and out_scale is None:
-            rc = lib.ideas_conv_direct(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(bias), _lib.ptr(resid),
+            rc = lib.ideas_conv_direct(_lib.ptr(y), _lib.ptr(x), _lib.ptr(L.wmat), None, None, _lib.ptr(bias), _lib.ptr(resid),
                                        C.byref(p), _lib.BF16, _lib.stream_ptr())
             _lib.check(rc, "ideas_conv_direct[bf16]")
             return
@@ -144,20 +156,12 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
         y.copy_(y32)
         return
     if MATH == _lib.F32_B3 and lib.ideas_b3_conv_supported(C.byref(p)):
-        k = L.TY * L.TX * L.Cin
-
-        def split():
-            pl = torch.empty(3 * L.Cout * k, device=x.device, dtype=torch.bfloat16)
-            _lib.check(lib.ideas_b3_split_weights(_lib.ptr(pl), _lib.ptr(w), L.Cout, k, L.Cin, _lib.stream_ptr()),
-                       "ideas_b3_split_weights")
-            return pl
-        planes = conv_plan.cached(L.wsrc, ("b3",) + L.wkey, split) if L.wsrc is not None else split()
-        rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(planes), _lib.ptr(in_scale), _lib.ptr(out_scale),
+        rc = lib.ideas_conv_igemm(_lib.ptr(y), _lib.ptr(x), _lib.ptr(b3_planes(L)), _lib.ptr(in_scale), _lib.ptr(out_scale),
                                   _lib.ptr(bias), _lib.ptr(resid), C.byref(p), _lib.F32_B3, _lib.stream_ptr())
         _lib.check(rc, "ideas_conv_igemm[b3]")
         return
     fn = lib.ideas_conv_igemm if (L.Cin % 4 == 0) else lib.ideas_conv_direct
-    rc = fn(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(bias),
+    rc = fn(_lib.ptr(y), _lib.ptr(x), _lib.ptr(L.wmat), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(bias),
             _lib.ptr(resid), C.byref(p), _lib.F32, _lib.stream_ptr())
     _lib.check(rc, "ideas_conv_igemm" if L.Cin % 4 == 0 else "ideas_conv_direct")
 

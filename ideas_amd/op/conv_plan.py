@@ -39,7 +39,9 @@ class ConvGeom:
 
 @dataclass
 class Launch:
-    """One kernel launch: integer fields of ideas_conv_params + the dense [Cout, TY*TX*Cin] weight matrix."""
+    """One kernel launch: integer fields of ideas_conv_params + the [Cout, TY, TX, Cin] weight matrix of the launch as a strided
+    VIEW of the parameter (``wview``: no device work).  The b3 / bf16 operand preparation reads it through its strides
+    (ideas_*_strided); ``wmat`` materialises the dense f32 copy only for the kernels that take one."""
     B: int
     IH: int
     IW: int
@@ -62,10 +64,18 @@ class Launch:
     ooy: int = 0
     oox: int = 0
     reflect: int = 0
-    wmat: Optional[torch.Tensor] = None      # forward family: [Cout, TY, TX, Cin] contiguous
-    wsrc: Optional[torch.Tensor] = None      # the parameter (view) wmat was derived from, and how: cache key for
-    wkey: Optional[tuple] = None             # further derived forms (split-bf16 planes)
+    wview: Optional[torch.Tensor] = None     # forward family: [Cout, TY, TX, Cin] view of the parameter
+    wsrc: Optional[torch.Tensor] = None      # the parameter (view) it was derived from, and how: cache key for
+    wkey: Optional[tuple] = None             # the derived forms (dense f32 copy, split-bf16 planes, bf16 pack)
     w_slice: Optional[Tuple[int, int]] = None  # wgrad of a phase: (cy, cx) tap offsets inside the full kernel
+
+    @property
+    def wmat(self) -> Optional[torch.Tensor]:
+        """Dense f32 [Cout, TY, TX, Cin] (free when the view is already contiguous, e.g. a channels_last parameter)."""
+        v = self.wview
+        if v is None or v.is_contiguous():
+            return v
+        return v.contiguous() if self.wsrc is None else cached(self.wsrc, ("dense",) + self.wkey, v.contiguous)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -108,18 +118,13 @@ def cached(w: torch.Tensor, key, make):
     return v
 
 
-def w_ohwi(w: torch.Tensor) -> torch.Tensor:
-    """[O, I, KH, KW] parameter -> [O, KH, KW, I] contiguous (a view when the parameter is channels_last)."""
-    return w.permute(0, 2, 3, 1).contiguous()
-
-
 def plan_fwd(x_shape, w: torch.Tensor, g: ConvGeom) -> Launch:
     b, ci, ih, iw = x_shape
     co = w.shape[0]
     oh, ow = g.out_size(ih, iw)
     return Launch(B=b, IH=ih, IW=iw, Cin=ci, YH=oh, YW=ow, Cout=co, OH=oh, OW=ow, TY=g.kh, TX=g.kw,
                   sy=g.stride, sx=g.stride, dy=1, dx=1, offy=-g.pad, offx=-g.pad, reflect=int(g.reflect),
-                  wmat=w_ohwi(w), wsrc=w, wkey=("fwd",))
+                  wview=w.permute(0, 2, 3, 1), wsrc=w, wkey=("fwd",))
 
 
 def _phase(r: int, p: int, s: int, k: int):
@@ -152,10 +157,9 @@ def plan_dgrad(gy_shape, w: torch.Tensor, g: ConvGeom, in_hw: Tuple[int, int]) -
                 need_zero = True
                 continue
             # wmat[i][(jy, jx, o)] = w[o][i][cy + s*jy][cx + s*jx]
-            wm = cached(w, ("dgrad", s, cy, cx), lambda: w[:, :, cy::s, cx::s].permute(1, 2, 3, 0).contiguous())
             launches.append(Launch(B=b, IH=oh, IW=ow, Cin=co, YH=ih, YW=iw, Cout=ci, OH=nqy, OW=nqx, TY=jy, TX=jx,
                                    sy=1, sx=1, dy=-1, dx=-1, offy=ey, offx=ex, osy=s, osx=s, ooy=ry, oox=rx,
-                                   wmat=wm, wsrc=w, wkey=("dgrad", s, cy, cx)))
+                                   wview=w[:, :, cy::s, cx::s].permute(1, 2, 3, 0), wsrc=w, wkey=("dgrad", s, cy, cx)))
     return launches, need_zero
 
 

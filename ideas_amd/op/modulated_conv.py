@@ -9,7 +9,8 @@ per call and runs a ``groups=batch`` conv (B small convs for cuDNN).  Here the a
 so ONE implicit GEMM with the shared weight serves the whole batch: ``s`` scales the activation tile while it
 is staged into LDS, ``d`` scales the accumulator in the epilogue (kernel: csrc/conv_igemm.hip).  The
 demodulation factor d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[o,i] + 1e-8), wsq = scale^2 * sum_k W^2, is a
-wavefront-shuffle reduction (csrc/modconv_aux.hip) instead of a pass over the per-sample weights.
+wavefront-shuffle reduction (csrc/modconv_aux.hip) instead of a pass over the per-sample weights; its derivative (to the style
+and to W) is folded into the backward of the conv Functions (ideas_demod_bwd, ideas_demod_wgrad).
 Difference to the reference's association is f32-roundoff class (SURVEY.md §7 measured 1.8e-6 abs on |y|~4).
 """
 from __future__ import annotations
@@ -25,6 +26,7 @@ from .. import _lib
 from ..precision import to_act, to_f32
 from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, weight_grad, _nhwc
 from .conv_plan import ConvGeom, convT_out_size
+from . import conv_plan
 from . import scratch
 from .upfirdn2d import upfirdn2d
 from .fused_act import fused_leaky_relu
@@ -44,37 +46,66 @@ def pixel_dot(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     return out
 
 
-class _Demod(Function):
-    """d = rsqrt((s*s) @ wsq^T + eps) on the shuffle-reduction kernel; backward is three tiny matmuls."""
+def weight_sqsum(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """wsq[o,i] = scale^2 * sum_k W[o,i,k]^2 (one kernel over the parameter in whatever strides it has; memoised per optimiser
+    step like the other derived weights)."""
+    def make():
+        cout, cin, kh, kw = w.shape
+        wsq = torch.empty((cout, cin), device=w.device, dtype=torch.float32)
+        so, si, sky, skx = w.stride()
+        _lib.check(_lib.load().ideas_weight_sqsum(_lib.ptr(wsq), _lib.ptr(w), cout, cin, kh, kw, so, si, sky, skx, float(scale * scale),
+                                                  _lib.stream_ptr()), "ideas_weight_sqsum")
+        return wsq
+    return conv_plan.cached(w, ("wsq", float(scale)), make)
 
-    @staticmethod
-    def forward(ctx, s, wsq, eps):
-        s, wsq = s.contiguous(), wsq.contiguous()
-        b, cin = s.shape
-        cout = wsq.shape[0]
-        d = torch.empty((b, cout), device=s.device, dtype=torch.float32)
-        rc = _lib.load().ideas_demod(_lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq), b, cin, cout, float(eps), _lib.stream_ptr())
-        _lib.check(rc, "ideas_demod")
-        ctx.save_for_backward(s, wsq, d)
-        return d
 
-    @staticmethod
-    def backward(ctx, gd):
-        s, wsq, d = ctx.saved_tensors
-        gq = -0.5 * gd * d * d * d                    # dq of (q + eps)^(-1/2)
-        gs = 2.0 * s * (gq @ wsq) if ctx.needs_input_grad[0] else None
-        gwsq = gq.t() @ (s * s) if ctx.needs_input_grad[1] else None
-        return gs, gwsq, None
+def demod_raw(s: torch.Tensor, wsq: torch.Tensor, eps: float) -> torch.Tensor:
+    """d[b,o] = rsqrt((s*s) @ wsq^T + eps) on the shuffle-reduction kernel (no autograd: the modulated-conv Functions own the
+    derivative, _style_grads / _demod_wgrad)."""
+    b, cin = s.shape
+    cout = wsq.shape[0]
+    d = torch.empty((b, cout), device=s.device, dtype=torch.float32)
+    rc = _lib.load().ideas_demod(_lib.ptr(d), _lib.ptr(s), _lib.ptr(wsq), b, cin, cout, float(eps), _lib.stream_ptr())
+    _lib.check(rc, "ideas_demod")
+    return d
+
+
+def _style_grads(dot_s, dot_d, s, d, w, gain: float):
+    """(gs, gq) of one modulated conv from its two per-sample reductions: the direct term <x, dL/d(s x)> = dot_s / s and the
+    term through the demodulation d(s, W), in one kernel (ideas_demod_bwd).  gq[b,o] = dL/dq of d = rsqrt(q + eps) is what
+    the weight gradient through the demodulation needs (_demod_wgrad).
+    Where s == 0 exactly the direct quotient is undefined and 0 is used (the true value needs a second, unscaled
+    input-gradient launch; s = affine(style) with bias 1 never hits an exact zero in training — DESIGN.md §5)."""
+    b, cin = s.shape
+    gs = torch.empty_like(s)
+    gq = wsq = None
+    cout = w.shape[0]
+    if d is not None:
+        gq, wsq = torch.empty_like(d), weight_sqsum(w, gain)
+    rc = _lib.load().ideas_demod_bwd(_lib.ptr(gs), _lib.ptr(gq), _lib.ptr(dot_s), _lib.ptr(dot_d), _lib.ptr(d), _lib.ptr(s),
+                                     _lib.ptr(wsq), b, cin, cout, _lib.stream_ptr())
+    _lib.check(rc, "ideas_demod_bwd")
+    return gs, gq
+
+
+def _demod_wgrad(gw: torch.Tensor, w: torch.Tensor, gq: torch.Tensor, s: torch.Tensor, gain: float) -> None:
+    """gw[o,i,k] += 2 gain^2 W[o,i,k] * sum_b gq[b,o] s[b,i]^2: the weight gradient through wsq, added in place."""
+    cout, cin, kh, kw = w.shape
+    rc = _lib.load().ideas_demod_wgrad(_lib.ptr(gw), _lib.ptr(w), _lib.ptr(gq), _lib.ptr(s), s.shape[0], cout, cin, kh, kw,
+                                       *w.stride(), *gw.stride(), float(2.0 * gain * gain), _lib.stream_ptr())
+    _lib.check(rc, "ideas_demod_wgrad")
 
 
 class _ModConv(Function):
-    """y = gain * d[b,o] * conv(s[b,i] * x, W)   (same-res, pad 1)  or the stride-2 transposed variant."""
+    """y = gain * d[b,o] * conv(s[b,i] * x, W)   (same-res, pad 1)  or the stride-2 transposed variant, with the demodulation
+    d = rsqrt(sum_i s^2 wsq + eps) (``demod``) computed and differentiated inside: the backward returns the complete style
+    gradient (direct + through d) and adds the through-d term to the weight gradient, 2 small kernels instead of ~20 tensor ops."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, up: bool, gain: float):
+    def forward(ctx, x, w, s, up: bool, gain: float, demod: bool, eps: float):
         x = _nhwc(x)
         s = s.contiguous()
-        d = None if d is None else d.contiguous()
+        d = demod_raw(s, weight_sqsum(w, gain), eps) if demod else None
         k = w.shape[2]
         if up:
             g = ConvGeom(k, k, 2, 0, False)
@@ -94,33 +125,34 @@ class _ModConv(Function):
         d = d if ctx.has_d else None
         g, gain = ctx.g, ctx.gain
         gy = _nhwc(gy)
-        need_x, need_w, need_s, need_d = ctx.needs_input_grad[:4]
-        gx = gw = gs = gd = None
+        need_x, need_w, need_s = ctx.needs_input_grad[:3]
+        gx = gw = gs = gq = None
         if need_x or need_s:
             if ctx.up:
                 gx = conv_fwd_raw(gy, w.transpose(0, 1), g, gain, lin=d, lout=s)
             else:
                 gx = conv_dgrad_raw(gy, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
+        if need_s or (need_w and d is not None):
+            dot_s = pixel_dot(x, gx) if need_s else scratch.zeros(tuple(s.shape), s.device)
+            gs, gq = _style_grads(dot_s, pixel_dot(gy, y) if d is not None else None, s, d, w, gain)
         if need_w:
             if ctx.up:
                 wt_shape = (w.shape[1], w.shape[0], w.shape[2], w.shape[3])
 
-                def up_grad(out):
-                    gwt = conv_wgrad_raw(x, gy, g, wt_shape, gain, lin=d, lout=s).transpose(0, 1)
-                    return gwt if out is None else out.add_(gwt)
-                gw = weight_grad(w, up_grad, x, gy, s, d)
+                def grad(out):
+                    r = conv_wgrad_raw(x, gy, g, wt_shape, gain, lin=d, lout=s,
+                                       out=None if out is None else out.transpose(0, 1)).transpose(0, 1)
+                    if gq is not None:
+                        _demod_wgrad(r, w, gq, s, gain)
+                    return r
             else:
-                gw = weight_grad(w, lambda out: conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out),
-                                 x, gy, s, d)
-        if need_s:
-            # gx = s * (dL/d(s*x)); <x, gx> / s = <x, dL/d(s*x)>.  Where s == 0 exactly the quotient is undefined and 0 is
-            # returned (the true value needs a second, unscaled input-gradient launch; s = affine(style) with bias 1 never
-            # hits an exact zero in training — DESIGN.md §5)
-            dot = pixel_dot(x, gx)
-            gs = torch.where(s != 0, dot / s, torch.zeros_like(dot))
-        if need_d and d is not None:
-            gd = pixel_dot(gy, y) / d
-        return (gx if need_x else None), gw, gs, gd, None, None
+                def grad(out):
+                    r = conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out)
+                    if gq is not None:
+                        _demod_wgrad(r, w, gq, s, gain)
+                    return r
+            gw = weight_grad(w, grad, x, gy, s, d, gq)
+        return (gx if need_x else None), gw, (gs if need_s else None), None, None, None, None
 
 
 def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: float, act_gain: float, bias_grad_into=None):
@@ -141,15 +173,16 @@ def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: 
 
 
 class _ModConvAct(Function):
-    """Same-resolution modulated conv with bias + leaky-ReLU in the epilogue (StyledConv_without_noise,
+    """Same-resolution demodulated conv with bias + leaky-ReLU in the epilogue (StyledConv_without_noise,
     stylegan2/model.py:371-377).  Only the post-activation output is kept for the backward; the pre-activation
     needed by d(demod) is recovered inside the fused backward-prologue kernel (ideas_act_bwd_dot)."""
 
     @staticmethod
-    def forward(ctx, x, w, s, d, b, gain: float, slope: float, act_gain: float):
+    def forward(ctx, x, w, s, b, gain: float, slope: float, act_gain: float, eps: float):
         x = _nhwc(x)
         bias_param = b
-        s, d, b = s.contiguous(), d.contiguous(), b.contiguous()
+        s, b = s.contiguous(), b.contiguous()
+        d = demod_raw(s, weight_sqsum(w, gain), eps)
         k = w.shape[2]
         g = ConvGeom(k, k, 1, k // 2, False)
         y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d, bias=b, act=True, act_gain=act_gain, alpha=slope)
@@ -163,21 +196,22 @@ class _ModConvAct(Function):
     def backward(ctx, gy):
         x, w, s, d, b, y = ctx.saved_tensors
         g, gain = ctx.g, ctx.gain
-        need_x, need_w, need_s, need_d, need_b = ctx.needs_input_grad[:5]
+        need_x, need_w, need_s, need_b = ctx.needs_input_grad[:4]
         from .fused_act import bias_sink
-        gpre, gb, dot = act_bwd_dot(gy, y, b, ctx.slope, ctx.act_gain, bias_grad_into=bias_sink(ctx.bias_ref) if need_b else None)
-        gx = gw = gs = gd = None
+        gpre, gb, dot_d = act_bwd_dot(gy, y, b, ctx.slope, ctx.act_gain, bias_grad_into=bias_sink(ctx.bias_ref) if need_b else None)
+        gx = gw = gs = gq = None
         if need_x or need_s:
             gx = conv_dgrad_raw(gpre, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
+        if need_s or need_w:
+            dot_s = pixel_dot(x, gx) if need_s else scratch.zeros(tuple(s.shape), s.device)
+            gs, gq = _style_grads(dot_s, dot_d, s, d, w, gain)
         if need_w:
-            gw = weight_grad(w, lambda out: conv_wgrad_raw(gpre, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out),
-                             gpre, x, s, d)
-        if need_s:
-            ds = pixel_dot(x, gx)
-            gs = torch.where(s != 0, ds / s, torch.zeros_like(ds))
-        if need_d:
-            gd = dot / d
-        return (gx if need_x else None), gw, gs, gd, (gb if need_b else None), None, None, None     # gb is None when sunk
+            def grad(out):
+                r = conv_wgrad_raw(gpre, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out)
+                _demod_wgrad(r, w, gq, s, gain)
+                return r
+            gw = weight_grad(w, grad, gpre, x, s, d, gq)
+        return (gx if need_x else None), gw, (gs if need_s else None), (gb if need_b else None), None, None, None, None
 
 
 _SECOND_ORDER = [False]
@@ -236,21 +270,19 @@ def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
     if _SECOND_ORDER[0] and torch.is_grad_enabled() and resid is None:
         return _modulated_conv2d_composite(x, w, style, demodulate, upsample, fir, eps, act_bias, negative_slope, act_scale)
     scale = 1.0 / math.sqrt(cin * k * k)
-    d = None
-    if demodulate:
-        wsq = (w * w).sum(dim=(2, 3)) * (scale * scale)
-        d = _Demod.apply(style, wsq, eps)
     fuse_act = act_bias is not None and not upsample and demodulate and cout % 4 == 0
     if resid is not None:
         if not fuse_act or torch.is_grad_enabled():
             raise RuntimeError("modulated_conv2d(resid=...) is the no-grad fast path of the fused same-resolution conv")
         k_ = w.shape[2]
-        return conv_fwd_raw(x, w, ConvGeom(k_, k_, 1, k_ // 2, False), scale, lin=style.contiguous(), lout=d.contiguous(),
+        style = style.contiguous()
+        d = demod_raw(style, weight_sqsum(w, scale), eps)
+        return conv_fwd_raw(x, w, ConvGeom(k_, k_, 1, k_ // 2, False), scale, lin=style, lout=d,
                             bias=act_bias.contiguous(), act=True, act_gain=float(act_scale), alpha=float(negative_slope),
                             resid=resid, resid_gain=1.0)
     if fuse_act:
-        return _ModConvAct.apply(x, w, style, d, act_bias, scale, float(negative_slope), float(act_scale))
-    y = _ModConv.apply(x, w, style, d, upsample, scale)
+        return _ModConvAct.apply(x, w, style, act_bias, scale, float(negative_slope), float(act_scale), float(eps))
+    y = _ModConv.apply(x, w, style, upsample, scale, bool(demodulate), float(eps))
     if upsample:
         if fir is None:
             raise RuntimeError("modulated_conv2d(upsample=True) needs the blur FIR")

@@ -135,6 +135,12 @@ int ideas_b3_conv_supported(const ideas_conv_params* p);
 int ideas_b3_wgrad_supported(const ideas_conv_params* p);   /* 1 if ideas_conv_wgrad(IDEAS_F32_B3) runs the split kernel; otherwise it
                                                                 runs the IDEAS_F32 kernel (same arguments, same result class) */
 int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream);
+/* The same planes read straight from a parameter of any strides: element (n, ty, tx, ci) of the launch's weight matrix is
+ * w[n*sn + ty*sty + tx*stx + ci*sc] (floats; w already points at the first element).  Covers the forward matrix of an
+ * [O,I,KH,KW] tensor in either memory format, the phase-sliced transposed matrix of an input gradient (tap step = the conv
+ * stride) and the matrix of a transposed conv, without materialising a permuted / sliced f32 copy first. */
+int ideas_b3_split_weights_strided(void* planes, const float* w, int Cout, int TY, int TX, int Cin, int64_t sn, int64_t sty,
+                                   int64_t stx, int64_t sc, void* stream);
 /* The same for ideas_conv3x3_wino(IDEAS_F32_B3): Winograd-transformed AND split weights, 12*N*3*C bf16 laid out
  * [4 v][3 planes][3*C/16 steps][N][16] (step = (c/16)*3 + ky).  Element (n, ky, kx, c) of the 3x3 kernel is read at
  * w[base + n*sn + ky*sky + kx*skx + c*sc] (floats), so the forward matrix (n = o, c = i) and the flipped / transposed one
@@ -159,6 +165,9 @@ int ideas_b3_wino_split_weights(void* planes, const void* w, int N, int C, int64
 int ideas_bf16_conv_supported(const ideas_conv_params* p, int scaled);
 int ideas_bf16_wgrad_supported(const ideas_conv_params* p, int scaled);
 int ideas_bf16_pack_weights(void* pack, const void* wmat, const float* in_scale, int B, int Cout, int K, int Cin, void* stream);
+/* ideas_bf16_pack_weights reading the matrix through strides (see ideas_b3_split_weights_strided). */
+int ideas_bf16_pack_weights_strided(void* pack, const float* w, const float* in_scale, int B, int Cout, int TY, int TX, int Cin,
+                                    int64_t sn, int64_t sty, int64_t stx, int64_t sc, void* stream);
 /* 1 if ideas_conv_direct / ideas_conv_wgrad_direct with IDEAS_BF16 are the intended path for the geometry: the HBM-bound
  * pointwise layers with <= 8 input or output channels (from-RGB, to-RGB and their gradients).  Everything else without a bf16
  * MFMA kernel (a handful of tiny layers) is computed by the caller in f32 on casts. */
@@ -202,6 +211,19 @@ int ideas_conv_wgrad_direct(float* gw, const void* gy, const void* x, const floa
  * where wsq[o,i] = scale^2 * sum_k W[o,i,k]^2.  One wavefront per (b,o), shuffle reduction over Cin.
  * ---------------------------------------------------------------------------------------------- */
 int ideas_demod(float* d, const float* s, const float* wsq, int B, int Cin, int Cout, float eps, void* stream);
+/* wsq[o][i] = scale2 * sum_{ky,kx} W[o][i][ky][kx]^2 of a 4-D f32 weight of strides (so, si, sky, skx) (elements). */
+int ideas_weight_sqsum(float* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky, int64_t skx,
+                       float scale2, void* stream);
+/* Style gradient of a modulated conv from the per-sample reductions of its backward (ideas_pixel_dot / ideas_act_bwd_dot):
+ *   gq[b,o] = -0.5 * dot_d[b,o] * d[b,o]^2                 (dL/dq of d = rsqrt(q + eps); dot_d = <gy, y>, y = d * conv)
+ *   gs[b,i] = (s != 0 ? dot_s[b,i] / s[b,i] : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (dot_s = <x, gx>, gx = s * dL/d(s x))
+ * d == NULL (no demodulation): only the first term of gs; gq / dot_d / wsq are then unused. */
+int ideas_demod_bwd(float* gs, float* gq, const float* dot_s, const float* dot_d, const float* d, const float* s, const float* wsq,
+                    int B, int Cin, int Cout, void* stream);
+/* Weight gradient through the demodulation, ADDED in place:  gw[o][i][k] += coef * W[o][i][k] * sum_b gq[b,o] * s[b,i]^2
+ * (coef = 2 * scale^2).  W has strides (so, si, sky, skx), gw strides (go, gi, gky, gkx). */
+int ideas_demod_wgrad(float* gw, const float* w, const float* gq, const float* s, int B, int Cout, int Cin, int KH, int KW, int64_t so,
+                      int64_t si, int64_t sky, int64_t skx, int64_t go, int64_t gi, int64_t gky, int64_t gkx, float coef, void* stream);
 
 /* Per-(b,c) sum over pixels of a[b,p,c]*g[b,p,c] (NHWC).  Gives d(style) and d(demod) of the modulated conv
  * without materialising per-sample weights.  out must be ZEROED float[B*C]. */

@@ -122,6 +122,11 @@ def modulated_conv2d(x: Tensor, style: Tensor, weight: Tensor, mod_w: Tensor, mo
     if demodulate:
         d = torch.rsqrt(wt.pow(2).sum([2, 3, 4]) + 1e-8)
         wt = wt * d.view(b, cout, 1, 1, 1)
+    # The reference's parameter is dense, so are its per-sample weights.  A caller may hand in the same values in another memory
+    # order (ideas_amd keeps this parameter kernel-native); the elementwise ops above inherit those strides and PyTorch's CPU
+    # grouped-conv BACKWARD returns a wrong input gradient for such a weight view (checked against finite differences,
+    # torch 2.10) — so densify before the conv calls.
+    wt = wt.contiguous()
     if upsample:
         xin = x.reshape(1, b * cin, h, w_)
         wt = wt.transpose(1, 2).reshape(b * cin, cout, k, k)

@@ -664,3 +664,110 @@ def test_b3_full_size_properties():
         assert rel_err(y4, y8[:, :64]) < 2e-6
     finally:
         CV.MATH, CV.B3_WINO = math0, wino0
+
+
+# --------------------------------------------------------------------------------------------- operand preparation from strided views
+@pytest.mark.parametrize("case", [("fwd_cl", 64, 32, 3), ("fwd_nchw", 48, 64, 3), ("dgrad_s2", 64, 32, 3), ("dgrad_s1", 32, 64, 1),
+                                  ("convT", 32, 96, 3)])
+def test_weight_operands_from_strided_views_equal_the_dense_path(case):
+    """ideas_b3_split_weights_strided / ideas_bf16_pack_weights_strided read the launch's [Cout, TY, TX, Cin] matrix through the
+    strides of a parameter view (conv_plan.Launch.wview); bit-identical to the dense kernels on a materialised copy, for the
+    forward matrix of either memory format, the phase-sliced matrices of an input gradient and a transposed-conv reading."""
+    from ideas_amd import _lib
+    from ideas_amd.op.conv_plan import ConvGeom, plan_dgrad, plan_fwd
+    kind, co, ci, k = case
+    torch.manual_seed(co + ci)
+    w = torch.randn(co, ci, k, k, device="cuda")
+    if kind == "fwd_cl":
+        Ls = [plan_fwd((2, ci, 16, 16), w.contiguous(memory_format=CL), ConvGeom(k, k, 1, k // 2))]
+    elif kind == "fwd_nchw":
+        Ls = [plan_fwd((2, ci, 16, 16), w, ConvGeom(k, k, 1, k // 2))]
+    elif kind == "dgrad_s2":
+        Ls = plan_dgrad((2, co, 8, 8), w.contiguous(memory_format=CL), ConvGeom(k, k, 2, 1), (16, 16))[0]
+    elif kind == "dgrad_s1":
+        Ls = plan_dgrad((2, co, 8, 8), w.contiguous(memory_format=CL), ConvGeom(k, k, 1, 0), (8, 8))[0]
+    else:
+        Ls = plan_dgrad((2, ci, 8, 8), w.transpose(0, 1), ConvGeom(k, k, 2, 0), (17, 17))[0]      # w read as [I, O, k, k]
+    lib = _lib.load()
+    assert Ls
+    for L in Ls:
+        v, dense = L.wview, L.wmat
+        assert dense.is_contiguous() and tuple(dense.shape) == (L.Cout, L.TY, L.TX, L.Cin) and torch.equal(dense, v)
+        K = L.TY * L.TX * L.Cin
+        a = torch.zeros(3 * L.Cout * K, device="cuda", dtype=torch.bfloat16)
+        b = torch.zeros_like(a)
+        _lib.check(lib.ideas_b3_split_weights(_lib.ptr(a), _lib.ptr(dense), L.Cout, K, L.Cin, _lib.stream_ptr()), "split")
+        _lib.check(lib.ideas_b3_split_weights_strided(_lib.ptr(b), _lib.ptr(v), L.Cout, L.TY, L.TX, L.Cin, *v.stride(), _lib.stream_ptr()),
+                   "split_strided")
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (case, "b3")
+        sc = torch.rand(3, L.Cin, device="cuda") + 0.5
+        for scale, nb in ((None, 1), (sc, 3)):
+            a = torch.zeros(nb * L.Cout * K, device="cuda", dtype=torch.bfloat16)
+            b = torch.zeros_like(a)
+            _lib.check(lib.ideas_bf16_pack_weights(_lib.ptr(a), _lib.ptr(dense), _lib.ptr(scale), nb, L.Cout, K, L.Cin, _lib.stream_ptr()), "pack")
+            _lib.check(lib.ideas_bf16_pack_weights_strided(_lib.ptr(b), _lib.ptr(v), _lib.ptr(scale), nb, L.Cout, L.TY, L.TX, L.Cin, *v.stride(),
+                                                           _lib.stream_ptr()), "pack_strided")
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (case, "bf16", nb)
+
+
+@pytest.mark.parametrize("up", [False, True])
+def test_demodulation_kernels_vs_float64(up):
+    """ideas_weight_sqsum / ideas_demod_bwd / ideas_demod_wgrad against the float64 autograd of
+    d = rsqrt((s*s) @ wsq^T + eps), wsq = scale^2 sum_k W^2 (stylegan2/model.py:243-244), in both weight memory orders."""
+    from ideas_amd.model import modconv_weight_layout
+    from ideas_amd.op import modulated_conv as MC
+    torch.manual_seed(5 + up)
+    B, co, ci, scale = 3, 40, 72, 0.11
+    w = modconv_weight_layout(torch.randn(1, co, ci, 3, 3), up).cuda()[0]
+    assert not w.is_contiguous()
+    s = torch.randn(B, ci, device="cuda")
+    s[1, 5] = 0.0
+    wsq = MC.weight_sqsum(w, scale)
+    w64 = w.double().requires_grad_(True)
+    s64 = s.double().requires_grad_(True)
+    wsq64 = (w64 * w64).sum((2, 3)) * scale * scale
+    assert rel_err(wsq, wsq64) < 1e-6
+    d64 = torch.rsqrt((s64 * s64) @ wsq64.t() + 1e-8)
+    d = MC.demod_raw(s, wsq, 1e-8)
+    assert rel_err(d, d64) < 1e-6
+    dot_d, dot_s = torch.randn(B, co, device="cuda"), torch.randn(B, ci, device="cuda")
+    gd64 = dot_d.double() / d64.detach()
+    gs_ref, gw_ref = torch.autograd.grad(d64, (s64, w64), gd64)
+    direct = torch.where(s64 != 0, dot_s.double() / s64, torch.zeros_like(s64)).detach()
+    gs, gq = MC._style_grads(dot_s, dot_d, s, d, w, scale)
+    assert rel_err(gs, gs_ref + direct) < 1e-5, rel_err(gs, gs_ref + direct)
+    assert gs[1, 5].item() == pytest.approx(gs_ref[1, 5].item(), abs=1e-6)       # s == 0: the direct term is dropped, not NaN
+    gw = torch.randn(co, 3, 3, ci, device="cuda").permute(0, 3, 1, 2)             # accumulate into a differently-strided buffer
+    before = gw.clone()
+    MC._demod_wgrad(gw, w, gq, s, scale)
+    assert rel_err(gw - before, gw_ref) < 1e-5, rel_err(gw - before, gw_ref)
+    gs0, gq0 = MC._style_grads(dot_s, None, s, None, w, scale)                    # no demodulation: direct term only
+    assert gq0 is None and rel_err(gs0, direct) < 1e-6
+
+
+def test_grad_sink_modulated_conv_and_linear(ops):
+    """Inside grad_sink the modulated convs (both weight layouts, with the through-demodulation term) and the equalised-lr
+    linear layers accumulate straight into .grad; equal to plain autograd, and twice that after two passes."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.model import EqualLinear, StyledConv_without_noise
+    torch.manual_seed(3)
+    B, R = 2, 8
+    c1 = StyledConv_without_noise(32, 64, 3, 48).cuda()
+    c2 = StyledConv_without_noise(64, 32, 3, 48, upsample=True).cuda()
+    lin = EqualLinear(32, 8, activation="fused_lrelu").cuda()
+    x = torch.randn(B, 32, R, R, device="cuda").contiguous(memory_format=CL)
+    st = torch.randn(B, 48, device="cuda")
+    params = [p for m in (c1, c2, lin) for p in m.parameters()]
+
+    def loss():
+        h = c2(c1(x, st), st)
+        return (lin(h.float().mean((2, 3))) ** 2).mean() + (h.float() ** 2).mean()
+    ref = torch.autograd.grad(loss(), params)
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    for _ in range(2):
+        with CV.grad_sink(params):
+            loss().backward()
+    torch.cuda.synchronize()
+    for p, g in zip(params, ref):
+        assert rel_err(p.grad, 2 * g) < 3e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))

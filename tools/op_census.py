@@ -8,6 +8,8 @@ from ideas_amd.models import init_model
 from ideas_amd.optim import fuse_optimizers
 
 B = int(os.environ.get("B", 8))
+from ideas_amd import precision
+precision.set_activation_dtype(os.environ.get("PRECISION", "f32"))
 dev = torch.device("cuda")
 args = TS.default_args(image_size=256, batch_size=B, N=1, num_iters=10 ** 9)
 torch.manual_seed(0)
@@ -24,7 +26,8 @@ torch.cuda.synchronize()
 import traceback
 from torch.utils._python_dispatch import TorchDispatchMode
 
-WANT = ("add", "add_", "fill_", "zero_", "mul", "mul_", "copy_", "div", "sum", "clone", "zeros", "zeros_like", "ones", "contiguous")
+WANT = ("add", "add_", "fill_", "zero_", "mul", "mul_", "copy_", "_to_copy", "div", "sum", "clone", "zeros", "zeros_like", "ones", "contiguous",
+        "where", "eq", "ne", "cat", "neg", "sub", "rsqrt", "pow", "mm", "addmm", "t", "empty_like")
 cnt = collections.Counter()
 
 
@@ -43,5 +46,6 @@ torch.autograd.set_multithreading_enabled(False)      # backward in this thread,
 with Census():
     TS.train_iteration(tr, args, X, 3)
 torch.cuda.synchronize()
-for (name, where, size), n in cnt.most_common(60):
+print("total", sum(cnt.values()))
+for (name, where, size), n in cnt.most_common(90):
     print(f"{n:5d}  {name:10s} {size:5s} {where}")

@@ -37,6 +37,8 @@ def wg(gw, gy, x, L, gain, in_scale=None, out_scale=None):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    from ideas_amd import precision
+    precision.set_activation_dtype(os.environ.get("PRECISION", "f32"))
     dev = torch.device("cuda")
     args = TS.default_args(image_size=256, batch_size=B, num_iters=10 ** 9)
     torch.manual_seed(0)
@@ -54,19 +56,21 @@ def main():
     del tr
     torch.cuda.empty_cache()
     rows = []
+    adt = precision.activation_dtype()
     for k, (cnt, L) in log.items():
         kind, scaled = k[0], k[-1]
-        x = torch.randn(L.B, L.Cin, L.IH, L.IW, device=dev).contiguous(memory_format=CL)
+        x = torch.randn(L.B, L.Cin, L.IH, L.IW, device=dev).to(adt).contiguous(memory_format=CL)
         lin = torch.rand(L.B, L.Cin, device=dev) + 0.5 if scaled else None
         lout = torch.rand(L.B, L.Cout, device=dev) + 0.5 if scaled else None
         flops = 2.0 * L.B * L.OH * L.OW * L.TY * L.TX * L.Cin * L.Cout
         if kind == "fwd":
-            y = torch.empty(L.B, L.Cout, L.YH, L.YW, device=dev).contiguous(memory_format=CL)
-            if L.wmat is None:
+            y = torch.empty(L.B, L.Cout, L.YH, L.YW, device=dev, dtype=adt).contiguous(memory_format=CL)
+            if L.wview is None:
                 continue
+            L.wview, L.wsrc = torch.randn(L.Cout, L.TY, L.TX, L.Cin, device=dev), None      # (the logged views are stale by now)
             fn = lambda: orig_fwd(y, x, L, 0.1, lin, lout)
         else:
-            gy = torch.randn(L.B, L.Cout, L.YH, L.YW, device=dev).contiguous(memory_format=CL)
+            gy = torch.randn(L.B, L.Cout, L.YH, L.YW, device=dev).to(adt).contiguous(memory_format=CL)
             gw = torch.zeros(L.Cout, L.TY, L.TX, L.Cin, device=dev)
             fn = lambda: orig_wg(gw, gy, x, L, 0.1, lin, lout)
         for _ in range(2):
