@@ -144,28 +144,31 @@ template <int SMALL, bool WIDE_OUT, typename T>
 __global__ __launch_bounds__(256) void pointwise_small_wgrad_kernel(float* __restrict__ gw, const T* __restrict__ gy,
                                                                     const T* __restrict__ x, int64_t P, int Cin, int Cout,
                                                                     float gain, int64_t pix_per_block) {
-    __shared__ float s_red[256 * 8];   // [wide][SMALL] block-level partial sums
+    __shared__ float s_red[512 * 8];   // [wide][SMALL] block-level partial sums (wide <= 512)
     const int wide = WIDE_OUT ? Cout : Cin, small = WIDE_OUT ? Cin : Cout;
-    const int groups = blockDim.x / wide;
-    const int c = threadIdx.x % wide, grp = threadIdx.x / wide;
+    const int lanes = wide < (int)blockDim.x ? wide : (int)blockDim.x;      // > 256 wide channels: each thread takes two
+    const int groups = blockDim.x / lanes;
+    const int c0 = threadIdx.x % lanes, grp = threadIdx.x / lanes;
     for (int i = threadIdx.x; i < wide * SMALL; i += blockDim.x) s_red[i] = 0.f;
     __syncthreads();
     if (grp < groups) {
         const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
         const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
-        float acc[SMALL];
+        for (int c = c0; c < wide; c += lanes) {
+            float acc[SMALL];
 #pragma unroll
-        for (int k = 0; k < SMALL; ++k) acc[k] = 0.f;
-        for (int64_t pp = p0 + grp; pp < p1; pp += groups) {
-            const float a = WIDE_OUT ? ldv(gy + pp * Cout + c) : ldv(x + pp * Cin + c);
-            const T* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
+            for (int k = 0; k < SMALL; ++k) acc[k] = 0.f;
+            for (int64_t pp = p0 + grp; pp < p1; pp += groups) {
+                const float a = WIDE_OUT ? ldv(gy + pp * Cout + c) : ldv(x + pp * Cin + c);
+                const T* bp = WIDE_OUT ? x + pp * Cin : gy + pp * Cout;
+#pragma unroll
+                for (int k = 0; k < SMALL; ++k)
+                    if (k < small) acc[k] = fmaf(a, ldv(bp + k), acc[k]);
+            }
 #pragma unroll
             for (int k = 0; k < SMALL; ++k)
-                if (k < small) acc[k] = fmaf(a, ldv(bp + k), acc[k]);
+                if (k < small) atomicAdd(&s_red[c * SMALL + k], acc[k]);   // LDS: fold the pixel groups of this block
         }
-#pragma unroll
-        for (int k = 0; k < SMALL; ++k)
-            if (k < small) atomicAdd(&s_red[c * SMALL + k], acc[k]);   // LDS: fold the pixel groups of this block
     }
     __syncthreads();
     // one global atomic per (block, output element): few blocks x few outputs, so no hot-address serialisation
@@ -394,7 +397,7 @@ int wgrad_direct_impl(float* gw, const void* gy, const void* x, const float* in_
             return ideas_launch_status();
         }
     }
-    if (is_pointwise(p) && !in_scale && !out_scale && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 256 && p->Cout <= 256) {
+    if (is_pointwise(p) && !in_scale && !out_scale && (p->Cin <= 8 || p->Cout <= 8) && p->Cin <= 512 && p->Cout <= 512) {
         int64_t blocks = ideas_cdiv(P, 512);
         if (blocks > 1024) blocks = 1024;
         const int64_t per = ideas_cdiv(P, blocks);

@@ -146,6 +146,168 @@ __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __
     }
 }
 
+// ---------------- NHWC 4x4 FIR with decimation by 2 (up = 1, down = 2) ----------------------------------------------------
+// The blur in front of a 1x1 stride-2 skip conv only feeds every second pixel of every second row into the conv
+// (models.py:78-95): computing it at the OUTPUT resolution writes N/4 instead of N and lets the conv run unstrided.
+// Same marching scheme as blur4_nhwc, the window advances two input rows per output row (8 loads, 1 store per output).
+template <typename V>
+__global__ __launch_bounds__(256) void fir4_down2_nhwc(V* __restrict__ y, const V* __restrict__ x, const float* __restrict__ fir,
+                                                       FirParams p) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    const int C4 = p.C >> 2;
+    const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * p.out_w * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int c4 = (int)(r % C4); r /= C4;
+    const int ox = (int)(r % p.out_w); r /= p.out_w;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int oy0 = seg * p.seg_rows;
+    const int oy1 = (oy0 + p.seg_rows < p.out_h) ? oy0 + p.seg_rows : p.out_h;
+    const int ix0 = 2 * ox - p.pad_x0;
+    float k[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) k[t] = sk[t];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const V* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
+    auto load_row = [&](int iy, float4 (&dst)[4]) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const V* xr = xb + ((int64_t)iy * p.in_w + ix0) * C4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float4 v = zero;
+            if (rowok && ((colmask >> t) & 1u)) v = to_f4(xr[(int64_t)t * C4]);
+            dst[t] = v;
+        }
+    };
+    float4 w[4][4];
+    load_row(2 * oy0 - p.pad_y0 + 0, w[0]);
+    load_row(2 * oy0 - p.pad_y0 + 1, w[1]);
+    V* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    for (int oy = oy0; oy < oy1; ++oy) {
+        load_row(2 * oy - p.pad_y0 + 2, w[2]);
+        load_row(2 * oy - p.pad_y0 + 3, w[3]);
+        float4 acc = zero;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float kk = k[4 * j + t];
+                acc.x = fmaf(w[j][t].x, kk, acc.x); acc.y = fmaf(w[j][t].y, kk, acc.y);
+                acc.z = fmaf(w[j][t].z, kk, acc.z); acc.w = fmaf(w[j][t].w, kk, acc.w);
+            }
+        yb[(int64_t)oy * p.out_w * C4] = from_f4<V>(acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { w[0][t] = w[2][t]; w[1][t] = w[3][t]; }
+    }
+}
+
+// ---------------- NHWC 4x4 FIR after zero-stuffing by 2 (up = 2, down = 1) ---------------------------------------------
+// The adjoint of the kernel above (its backward), and the blur behind a 1x1 stride-2 TRANSPOSED skip conv (three of four
+// pixels of that conv's output are structural zeros; here they are never written or read).  Per axis, output o = 2i + a
+// (a = 0, 1) sees the two taps k = k0(a), k0(a) + 2 with k0(a) = (pad0 - a) & 1, at inputs i + d(a), i + d(a) + 1,
+// d(a) = (a + k0(a) - pad0) / 2 -- so a 2 x 2 output block needs a 3 x 3 input neighbourhood.  A thread owns the output
+// column pair (2j, 2j + 1) of 4 channels and marches down block rows: 3 loads and 4 stores per block row.
+template <typename V>
+__global__ __launch_bounds__(256) void fir4_up2_nhwc(V* __restrict__ y, const V* __restrict__ x, const float* __restrict__ fir,
+                                                     FirParams p) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    const int C4 = p.C >> 2;
+    const int bh = (p.out_h + 1) >> 1, bw = (p.out_w + 1) >> 1;          // 2 x 2 output blocks
+    const int segs = (bh + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * bw * C4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int64_t r = idx;
+    const int c4 = (int)(r % C4); r /= C4;
+    const int j = (int)(r % bw); r /= bw;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int i0 = seg * p.seg_rows;
+    const int i1 = (i0 + p.seg_rows < bh) ? i0 + p.seg_rows : bh;
+    // per-axis tap / offset tables (a = output parity)
+    const int ky0[2] = {p.pad_y0 & 1, (p.pad_y0 - 1) & 1}, kx0[2] = {p.pad_x0 & 1, (p.pad_x0 - 1) & 1};
+    const int dy[2] = {(ky0[0] - p.pad_y0) >> 1, (1 + ky0[1] - p.pad_y0) >> 1};
+    const int dx[2] = {(kx0[0] - p.pad_x0) >> 1, (1 + kx0[1] - p.pad_x0) >> 1};
+    const int ey = dy[1] - dy[0], ex = dx[1] - dx[0];                       // 0 or 1: which 2 of the 3 rows / columns parity 1 uses
+    float wq[2][2][2][2];                                                  // [a][bb][u][v]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) wq[a][bb][u][v] = sk[(ky0[a] + 2 * u) * 4 + kx0[bb] + 2 * v];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const V* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
+    const int cx0 = j + dx[0];
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) colmask |= ((cx0 + t >= 0) && (cx0 + t < p.in_w)) ? (1u << t) : 0u;
+    auto load_row = [&](int iy, float4 (&dst)[3]) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const V* xr = xb + ((int64_t)iy * p.in_w + cx0) * C4;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float4 v = zero;
+            if (rowok && ((colmask >> t) & 1u)) v = to_f4(xr[(int64_t)t * C4]);
+            dst[t] = v;
+        }
+    };
+    float4 R[3][3];
+    load_row(i0 + dy[0] + 0, R[0]);
+    load_row(i0 + dy[0] + 1, R[1]);
+    const bool colB = 2 * j + 1 < p.out_w;
+    for (int i = i0; i < i1; ++i) {
+        load_row(i + dy[0] + 2, R[2]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = 2 * i + a;
+            if (oy >= p.out_h) break;
+            // rows of this parity: R[ra], R[ra + 1] with ra = a ? ey : 0 (selected without dynamic register indexing)
+            float4 top[3], bot[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool hi = (a == 1) && (ey == 1);
+                top[t] = hi ? R[1][t] : R[0][t];
+                bot[t] = hi ? R[2][t] : R[1][t];
+            }
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                if (bb == 1 && !colB) break;
+                const bool hx = (bb == 1) && (ex == 1);
+                const float4 t0 = hx ? top[1] : top[0], t1 = hx ? top[2] : top[1];
+                const float4 b0 = hx ? bot[1] : bot[0], b1 = hx ? bot[2] : bot[1];
+                const float w00 = wq[a][bb][0][0], w01 = wq[a][bb][0][1], w10 = wq[a][bb][1][0], w11 = wq[a][bb][1][1];
+                float4 acc;
+                acc.x = t0.x * w00 + t1.x * w01 + b0.x * w10 + b1.x * w11;
+                acc.y = t0.y * w00 + t1.y * w01 + b0.y * w10 + b1.y * w11;
+                acc.z = t0.z * w00 + t1.z * w01 + b0.z * w10 + b1.z * w11;
+                acc.w = t0.w * w00 + t1.w * w01 + b0.w * w10 + b1.w * w11;
+                y[(((int64_t)b * p.out_h + oy) * p.out_w + 2 * j + bb) * C4 + c4] = from_f4<V>(acc);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { R[0][t] = R[1][t]; R[1][t] = R[2][t]; }
+    }
+}
+
 // ---------------- bf16 NHWC 4x4 blur, 8 channels (16 bytes) per thread -------------------------------------------------
 // With 2-byte elements the 4-channel window kernel above moves half the bytes per instruction and is latency-bound
 // (1.45 TB/s measured).  Here a thread owns 8 channels of one output column.  A 4x4 window of 8-channel inputs would be 128
@@ -355,6 +517,32 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
                                (const ideas_bf16x4*)x, fir, p);
         else
             hipLaunchKernelGGL(blur4_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
+        return ideas_launch_status();
+    }
+    const bool vec4 = layout == IDEAS_NHWC && kh == 4 && kw == 4 && (C % 4 == 0) && ideas_aligned16(x) && ideas_aligned16(y);
+    if (vec4 && up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2) {
+        p.seg_rows = out_h >= 64 ? 16 : 8;
+        const int segs = (out_h + p.seg_rows - 1) / p.seg_rows;
+        const int64_t grid = ideas_cdiv((int64_t)B * segs * out_w * (C / 4), 256);
+        if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
+        if (dtype == IDEAS_BF16)
+            hipLaunchKernelGGL(fir4_down2_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
+                               (const ideas_bf16x4*)x, fir, p);
+        else
+            hipLaunchKernelGGL(fir4_down2_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
+        return ideas_launch_status();
+    }
+    if (vec4 && up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1) {
+        const int bh = (out_h + 1) / 2, bw = (out_w + 1) / 2;
+        p.seg_rows = bh >= 64 ? 16 : 8;
+        const int segs = (bh + p.seg_rows - 1) / p.seg_rows;
+        const int64_t grid = ideas_cdiv((int64_t)B * segs * bw * (C / 4), 256);
+        if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
+        if (dtype == IDEAS_BF16)
+            hipLaunchKernelGGL(fir4_up2_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
+                               (const ideas_bf16x4*)x, fir, p);
+        else
+            hipLaunchKernelGGL(fir4_up2_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
         return ideas_launch_status();
     }
     if (unit && layout == IDEAS_NCHW && kh <= 4 && kw <= 4) {

@@ -59,11 +59,18 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input, reflect_pad: int = 0, act: Optional[FusedLeakyReLU] = None, post_gain: float = 1.0,
-                resid: Optional[torch.Tensor] = None):
+                resid: Optional[torch.Tensor] = None, stride: Optional[int] = None):
         """``act``: the FusedLeakyReLU that follows in the ConvLayer — folded into the conv epilogue.
         ``post_gain``: extra scalar on the layer output (the residual blocks' 1/sqrt(2)), folded into the
-        activation gain / conv gain.  ``resid``: residual branch added in the epilogue (no-grad passes only)."""
+        activation gain / conv gain.  ``resid``: residual branch added in the epilogue (no-grad passes only).
+        ``stride``: override (a 1x1 stride-2 conv whose decimation the caller already did in the blur)."""
         pad, refl = (reflect_pad, True) if reflect_pad else (self.padding, False)
+        if stride is not None:
+            saved, self.stride = self.stride, stride
+            try:
+                return self.forward(input, reflect_pad, act, post_gain, resid)
+            finally:
+                self.stride = saved
         if act is not None and self.bias is None:
             return conv2d_bias_act(input, self.weight, act.bias, stride=self.stride, padding=pad, reflect=refl,
                                    gain=self.scale, negative_slope=act.negative_slope, scale=act.scale * post_gain,

@@ -20,7 +20,7 @@ from torch import nn
 
 from .model import (CL, Blur, EqualConv2d, EqualLinear, ScaledLeakyReLU,
                     StyledConv_without_noise as StyledConv)
-from .op import FusedLeakyReLU, conv_transpose2d
+from .op import FusedLeakyReLU, conv2d, conv_transpose2d, upfirdn2d
 from .precision import to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
@@ -107,6 +107,28 @@ class ConvLayer(nn.Sequential):
                 refl = m.padding[0]                            # mirror padding folded into the conv gather
                 i += 1
                 m = mods[i]
+            nxt_m = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(m, Blur) and isinstance(nxt_m, EqualConv2d) and nxt_m.stride == 2 and nxt_m.padding == 0
+                    and tuple(nxt_m.weight.shape[2:]) == (1, 1)):
+                # blur -> 1x1 stride-2 conv (downsampling skip, models.py:78-95): only every second blurred pixel is used, so
+                # the FIR is evaluated at the output resolution (down = 2) and the conv runs unstrided on a quarter of the pixels
+                x = upfirdn2d(x, m.kernel, down=2, pad=m.pad)
+                act = mods[i + 2] if i + 2 < len(mods) and isinstance(mods[i + 2], FusedLeakyReLU) else None
+                nxt = i + (3 if act is not None else 2)
+                if nxt < len(mods) and post_gain != 1.0:
+                    raise RuntimeError("post_gain needs the conv (+activation) to end the layer")
+                x = nxt_m(x, act=act, post_gain=post_gain, resid=resid, stride=1)
+                i = nxt
+                continue
+            if (isinstance(m, EqualConvTranspose2d) and isinstance(nxt_m, Blur) and m.stride == 2 and m.bias is None
+                    and tuple(m.weight.shape[2:]) == (1, 1)):
+                # 1x1 stride-2 transposed conv -> blur (upsampling skip): three of four pixels of the transposed conv's output are
+                # structural zeros.  The 1x1 conv runs at the input resolution and the FIR does the zero-stuffing (up = 2); the
+                # transposed conv's output is one pixel short of the zero-stuffed size, hence pad1 - 1.
+                x = conv2d(x, m.weight.transpose(0, 1), None, gain=m.scale * post_gain)
+                x = upfirdn2d(x, nxt_m.kernel, up=2, pad=(nxt_m.pad[0], nxt_m.pad[1] - 1))
+                i += 2
+                continue
             if isinstance(m, EqualConv2d):
                 act = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], FusedLeakyReLU) else None
                 nxt = i + (2 if act is not None else 1)

@@ -23,10 +23,10 @@ def key_of(kind, L, scaled):
             L.oox, L.reflect, scaled)
 
 
-def fwd(y, x, L, gain, in_scale=None, out_scale=None, bias=None, resid=None, **kw):
+def fwd(y, x, L, gain, in_scale=None, *a, **kw):
     k = key_of("fwd", L, in_scale is not None)
     log.setdefault(k, [0, L])[0] += 1
-    return orig_fwd(y, x, L, gain, in_scale, out_scale, bias, resid, **kw)
+    return orig_fwd(y, x, L, gain, in_scale, *a, **kw)
 
 
 def wg(gw, gy, x, L, gain, in_scale=None, out_scale=None):
