@@ -29,6 +29,19 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
 }
 
+// Split-K grids of the weight-gradient kernels: every tile of one K split reads the same pixels of gy / x, so the tiles of a
+// split should meet in ONE XCD's L2 instead of being dealt round-robin over the eight (each XCD would then fetch the split's
+// pixels from HBM itself).  1-D grid of tiles * splits blocks in split-major order, cut into eight contiguous bands by
+// xcd_swizzle: XCD k runs splits [k S/8, (k+1) S/8) with all their tiles, dispatched back to back; every XCD gets the same
+// number of blocks (+-1) whatever tiles and splits are.  Measured (tools/bench_igemm.py, B = 32): bf16 weight gradient of the
+// 128-channel layers at 256x256 384 -> 592 TFLOP/s, 64->128 @256x256 450 -> 647; split-bf16 kernels +2-5 %.
+static inline unsigned splitk_grid(int64_t tiles, int64_t splits) { return (unsigned)(tiles * splits); }
+__device__ __forceinline__ void splitk_xcd_map(int L, int tiles, int splits, int& tile, int& split) {
+    const int l = xcd_swizzle(L, tiles * splits);
+    split = l / tiles;
+    tile = l - split * tiles;
+}
+
 // ---- activation element access for the two storage dtypes: f32 arithmetic either way --------------------------------
 typedef unsigned short ideas_bf16;                 // one bf16 element in HBM
 struct ideas_bf16x4 { uint2 v; };                  // four consecutive bf16 (8 bytes)
@@ -84,6 +97,9 @@ int ideas_b3_wgrad(float* gw, const void* gy, const void* x, const float* in_sca
 // conv_b3_wino.hip: 3x3/s1/p1 Winograd F(2,3) with the split contraction (uplanes from ideas_b3_wino_split_weights)
 int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* in_scale, const float* out_scale,
                       const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);
+// conv_b3_wino_wgrad.hip: Winograd-domain weight gradient of the same layers with the split contraction (dU [4][Cout][3][Cin])
+int ideas_b3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                        const ideas_conv_params* p, hipStream_t stream);
 // conv_bf16.hip: bf16 mixed-precision family (dtype IDEAS_BF16): bf16 activations, packed bf16 weights (ideas_bf16_pack_weights)
 int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                    const void* resid, const ideas_conv_params* p, hipStream_t stream);

@@ -3,7 +3,7 @@
 //     gw[o][k] += gain * sum over pixels p of  G(p, o) * X(p, k)          k = (ty, tx, ci)
 //
 // GEMM view: M = Cout, N = TY*TX*Cin, reduction over the B*OH*OW output pixels, 16 pixels per pipeline step (= the K
-// of one v_mfma_f32_32x32x16_bf16), split-K over blockIdx.y with f32 atomics into the caller-zeroed gw.
+// of one v_mfma_f32_32x32x16_bf16), split-K (common.hpp: splitk_xcd_map) with f32 atomics into the caller-zeroed gw.
 //
 // Both operands are pixel-major in HBM (NHWC: channels contiguous), but the MFMA wants, per lane, 8 consecutive PIXELS
 // of one channel.  The transpose happens in registers on the way into LDS: a staging thread owns a 4-channel x
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_wgrad_kernel(float* __restrict
                                                                const float* __restrict__ in_scale,
                                                                const float* __restrict__ out_scale, ideas_conv_params p,
                                                                int tiles_n, int pix_per_split, unsigned gy_bytes,
-                                                               unsigned x_bytes) {
+                                                               unsigned x_bytes, int tiles, int splits) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * MT * 32;   // output channels of the tile
     constexpr int BN = WN * NT * 32;   // k columns of the tile
@@ -40,12 +40,14 @@ __global__ __launch_bounds__(256, 2) void conv_b3_wgrad_kernel(float* __restrict
 
     const int t = threadIdx.x;
     const int Ktot = p.TY * p.TX * p.Cin;
-    const int tile_n = blockIdx.x % tiles_n;
-    const int tile_m = blockIdx.x / tiles_n;
+    int tile, split;
+    splitk_xcd_map(blockIdx.x, tiles, splits, tile, split);
+    const int tile_n = tile % tiles_n;
+    const int tile_m = tile / tiles_n;
     const int o0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int P = p.B * p.OH * p.OW;
-    const int pbeg = blockIdx.y * pix_per_split;
+    const int pbeg = split * pix_per_split;
     const int pend = pbeg + pix_per_split < P ? pbeg + pix_per_split : P;
     if (pbeg >= pend) return;
 
@@ -246,8 +248,8 @@ int launch_b3_wgrad_cfg(float* gw, const void* gy, const void* x, const float* i
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
     auto go = [&](auto sc, auto rf) {
         hipLaunchKernelGGL((conv_b3_wgrad_kernel<WM, WN, MT, NT, decltype(sc)::value, decltype(rf)::value>),
-                           dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, stream, gw, (const float*)gy,
-                           (const float*)x, in_scale, out_scale, *p, tn, (int)per, gy_bytes, x_bytes);
+                           dim3(splitk_grid(tiles, splits)), dim3(256), 0, stream, gw, (const float*)gy,
+                           (const float*)x, in_scale, out_scale, *p, tn, (int)per, gy_bytes, x_bytes, (int)tiles, (int)splits);
     };
     using T = std::true_type;
     using F = std::false_type;

@@ -26,7 +26,7 @@
 //       rows of column l & 15 of a 4 x 16 block whose 8-byte pieces the 16 lanes of its group point at (probed:
 //       tools/probes/tr.hip).  16-byte chunks are XOR-swizzled across the four pixel rows of a block so that the 32 lanes of a
 //       half-wave hit 32 different bank pairs;
-//     * split-K over blockIdx.y with f32 atomics into the (flat-bucket) f32 gradient; for modulated convs every split lies
+//     * split-K (XCD-banded, common.hpp: splitk_xcd_map) with f32 atomics into the (flat-bucket) f32 gradient; for modulated convs every split lies
 //       inside one image and the per-sample scales d[b,o] * s[b,ci] are applied to the accumulator in the epilogue.
 #include "common.hpp"
 #include <type_traits>
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_wgrad_kernel(float* __
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ in_scale,
                                                                  const float* __restrict__ out_scale, ideas_conv_params p,
                                                                  int tiles_n, int pix_per_split, int splits_per_img,
-                                                                 unsigned gy_bytes, unsigned x_bytes) {
+                                                                 unsigned gy_bytes, unsigned x_bytes, int tiles, int splits) {
     constexpr int NW = WM * WN;        // waves per block (4 or 8)
     constexpr int BM = WM * MT * 32;   // output channels of the tile
     constexpr int BN = WN * NT * 32;   // k columns of the tile
@@ -406,13 +406,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_wgrad_kernel(float* __
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int Ktot = p.TY * p.TX * p.Cin;
-    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    int tile, split;
+    splitk_xcd_map(blockIdx.x, tiles, splits, tile, split);
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
     const int o0 = tile_m * BM, n0 = tile_n * BN;
     const int P = p.B * p.OH * p.OW;
     // plain: splits cut the flattened pixel axis; SCALE: `splits_per_img` splits per image, none straddles two samples
     const int OHW = p.OH * p.OW;
-    const int bimg = SCALE ? blockIdx.y / splits_per_img : 0;
-    const int pbeg = SCALE ? bimg * OHW + (blockIdx.y - bimg * splits_per_img) * pix_per_split : blockIdx.y * pix_per_split;
+    const int bimg = SCALE ? split / splits_per_img : 0;
+    const int pbeg = SCALE ? bimg * OHW + (split - bimg * splits_per_img) * pix_per_split : split * pix_per_split;
     const int plim = SCALE ? (bimg + 1) * OHW : P;
     const int pend = pbeg + pix_per_split < plim ? pbeg + pix_per_split : plim;
     if (pbeg >= pend) return;
@@ -642,13 +644,13 @@ int launch_bf16_wgrad_cfg(float* gw, const void* gy, const void* x, const float*
         per = ideas_cdiv(ideas_cdiv(P, splits), 32) * 32;
         splits = ideas_cdiv(P, per);
     }
-    if (splits > 65535) return IDEAS_E_SHAPE;
+    if (tiles * splits > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const unsigned gy_bytes = (unsigned)((int64_t)p->B * p->YH * p->YW * p->Cout * 2);
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
     auto go = [&](auto s_, auto rf) {
         hipLaunchKernelGGL((conv_bf16_wgrad_kernel<WM, WN, MT, NT, decltype(s_)::value, decltype(rf)::value>),
-                           dim3((unsigned)tiles, (unsigned)splits), dim3(64 * WM * WN), 0, stream, gw, (const bf16_t*)gy, (const bf16_t*)x,
-                           in_scale, out_scale, *p, tn, (int)per, (int)spi, gy_bytes, x_bytes);
+                           dim3(splitk_grid(tiles, splits)), dim3(64 * WM * WN), 0, stream, gw, (const bf16_t*)gy, (const bf16_t*)x,
+                           in_scale, out_scale, *p, tn, (int)per, (int)spi, gy_bytes, x_bytes, (int)tiles, (int)splits);
     };
     using T = std::true_type;
     using F = std::false_type;

@@ -450,6 +450,13 @@ extern "C" int ideas_conv3x3_wino(void* y, const void* x, const void* umat, cons
 // plus Cout % 4 == 0.  in_scale / out_scale: both or neither.
 extern "C" int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale,
                                         const float* out_scale, const ideas_conv_params* p, int dtype, void* stream_) {
+    if (dtype == IDEAS_F32_B3) {   // split-bf16 contraction (conv_b3_wino_wgrad.hip), same dU layout
+        if (!gu || !gy || !x || !p) return IDEAS_E_NULL;
+        if ((in_scale == nullptr) != (out_scale == nullptr) || !ideas_b3_wino_wgrad_supported(p)) return IDEAS_E_UNSUPPORTED;
+        if (!ideas_aligned16(x) || !ideas_aligned16(gy) || (in_scale && (!ideas_aligned16(in_scale) || !ideas_aligned16(out_scale))))
+            return IDEAS_E_ALIGN;
+        return ideas_b3_wino_wgrad(gu, gy, x, in_scale, out_scale, p, (hipStream_t)stream_);
+    }
     if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
     if (!gu || !gy || !x || !p) return IDEAS_E_NULL;
     if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;

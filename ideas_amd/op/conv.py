@@ -270,6 +270,33 @@ def conv_dgrad_fold32(gxp: torch.Tensor, in_hw, pad: int) -> torch.Tensor:
     return gx.to(BF)
 
 
+# Winograd-domain weight gradient of the split-bf16 path (csrc/conv_b3_wino_wgrad.hip): 2/3 of the products, but measured no
+# faster than the direct split weight-gradient kernel (the step is bound by operand staging, not by the matrix pipe: 159-199
+# against 161-184 TFLOP/s on the 128-512 channel layers, slower below; profiles/r02_wgrad_ab.txt), so it is OFF by default;
+# IDEAS_B3_WINO_WGRAD=1 selects it for the 3x3/s1 layers it supports.
+B3_WINO_WGRAD = _os.environ.get("IDEAS_B3_WINO_WGRAD", "0") == "1"
+_GU = {}
+
+
+def _wino_gu_scratch(n: int, device) -> torch.Tensor:
+    """ZEROED f32 scratch for the Winograd-domain gradient dU, one per (stream, size): the fold kernel re-zeroes it behind its
+    read, so it is filled once and never again.  Keyed by stream because the gradient sink runs weight gradients on its own."""
+    key = (torch.cuda.current_stream().cuda_stream, n, str(device))
+    buf = _GU.get(key)
+    if buf is None:
+        buf = _GU[key] = torch.zeros(n, device=device, dtype=torch.float32)
+    return buf
+
+
+def _wino_fold(gu, out, co: int, ci: int, w_shape, device, clear: bool = True):
+    """dU [4, O, 3, I] -> the 3x3 taps added into ``out`` (any strides) or into a fresh zeroed OHWI gradient."""
+    tgt = out if out is not None else torch.zeros(tuple(w_shape), device=device, dtype=torch.float32).contiguous(memory_format=CL)
+    so, si, sky, skx = tgt.stride()
+    rc = _lib.load().ideas_wino_wgrad_fold(_lib.ptr(tgt), _lib.ptr(gu), co, ci, so, sky, skx, si, int(clear), _lib.stream_ptr())
+    _lib.check(rc, "ideas_wino_wgrad_fold")
+    return tgt
+
+
 def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None, out=None):
     """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy.
     ``out`` (an OHWI-contiguous tensor of that shape): ADD the gradient to it instead of returning a new tensor — the
@@ -283,6 +310,18 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
     L = plan_wgrad(x.shape, gy.shape, g)
+    if x.dtype == torch.float32 and MATH == _lib.F32_B3 and B3_WINO_WGRAD and tuple(w_shape[2:]) == (3, 3) and g.stride == 1 \
+            and g.pad == 1:
+        b, ci, h, wd = x.shape
+        co = gy.shape[1]
+        p = _lib.ConvParams(b, h, wd, ci, h, wd, co, h, wd, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(g.reflect), 0, 0.2,
+                            1.0, 1.0, 0, gain)
+        if _lib.load().ideas_b3_wino_wgrad_supported(C.byref(p)):
+            gu = _wino_gu_scratch(4 * co * 3 * ci, x.device)
+            rc = _lib.load().ideas_conv3x3_wino_wgrad(_lib.ptr(gu), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(lin), _lib.ptr(lout),
+                                                      C.byref(p), _lib.F32_B3, _lib.stream_ptr())
+            _lib.check(rc, "ideas_conv3x3_wino_wgrad[b3]")
+            return _wino_fold(gu, out, co, ci, w_shape, x.device)
     b3 = x.dtype == BF or (MATH == _lib.F32_B3 and bool(_lib.load().ideas_b3_wgrad_supported(C.byref(_params(L, gain)))))
     if not b3 and _wino_ok(g, x.shape[1], x.shape[3], fwd=False) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
         b, ci, h, wd = x.shape
@@ -293,10 +332,7 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         rc = _lib.load().ideas_conv3x3_wino_wgrad(_lib.ptr(gu), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(lin), _lib.ptr(lout),
                                                   C.byref(p), _lib.F32, _lib.stream_ptr())
         _lib.check(rc, "ideas_conv3x3_wino_wgrad")
-        half = (gu[1] + gu[2]) * 0.5
-        dw = torch.stack((gu[0] + half, (gu[1] - gu[2]) * 0.5, half + gu[3]), dim=2)    # [O, ky, kx, I]
-        dw = dw.permute(0, 3, 1, 2)                                                    # [O, I, 3, 3], OHWI in memory
-        return dw if out is None else out.add_(dw)
+        return _wino_fold(gu, out, co, ci, w_shape, x.device, clear=False)
     if (lin is None) != (lout is None):   # the MFMA wgrad kernel takes both per-sample scales or neither
         if lin is None:
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)

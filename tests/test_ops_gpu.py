@@ -702,9 +702,17 @@ def test_b3_full_size_properties():
             lhs = float((gy.double() * y1.double()).sum())
             rhs = float((gx.double() * x1.double()).sum())
             assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3, (stride, lhs, rhs)
-            gw = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)
+            gw = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)      # direct split kernel
             lhs_w = float((gw.double() * w.double()).sum())
             assert abs(lhs_w - lhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-3, (stride, lhs_w, lhs)
+            if stride == 1:
+                ww0, CV.B3_WINO_WGRAD = CV.B3_WINO_WGRAD, True
+                try:
+                    gww = CV.conv_wgrad_raw(gy, x1, g, tuple(w.shape), gain)  # Winograd-domain split kernel
+                finally:
+                    CV.B3_WINO_WGRAD = ww0
+                assert rel_err(gww, gw) < 5e-6, rel_err(gww, gw)
+                del gww
             del y1, y2, y12, yd, yf, gy, gx, gw
         # the 4-wave and the 8-wave Winograd tiles are the same arithmetic in a different order
         g = ConvGeom(3, 3, 1, 1, False)
@@ -714,6 +722,63 @@ def test_b3_full_size_properties():
         assert rel_err(y4, y8[:, :64]) < 2e-6
     finally:
         CV.MATH, CV.B3_WINO = math0, wino0
+
+
+B3_WINO_WGRAD_CASES = [
+    # B, Cin, Cout, H, W, reflect, scaled            (B*H*W/2 >= 16384: below that the dispatch keeps the direct split kernel)
+    (2, 32, 64, 64, 256, False, False),     # 64 x 192 tile, half-empty (ky, ci) tile
+    (2, 64, 128, 128, 128, False, True),    # 64 x 192 tile, two channel tiles, per-sample scales
+    (1, 128, 72, 128, 256, False, False),   # 128 x 128 tile, channel rows past Cout
+    (4, 32, 64, 64, 128, True, False),      # mirrored padding
+    (32, 16, 40, 64, 16, False, True),      # W/2 = 8: a 16-pair step spans two rows
+    (16, 16, 64, 64, 32, False, False),     # W/2 = 16: exactly one row per step
+]
+
+
+@pytest.mark.parametrize("case", B3_WINO_WGRAD_CASES)
+def test_b3_winograd_weight_gradient_vs_oracle_and_direct(case):
+    """conv_b3_wino_wgrad.hip (Winograd-domain split-bf16 weight gradient + ideas_wino_wgrad_fold) against f64 autograd and the
+    direct split kernel on the same inputs; accumulating into an existing gradient adds; the dU scratch comes back zeroed."""
+    import ctypes as C
+    import ideas_amd.op.conv as CV
+    from ideas_amd import _lib
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, refl, scaled = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    s = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if scaled else None
+    d = (torch.rand(B, co, dtype=torch.float64) + 0.5) if scaled else None
+    gy = torch.randn(B, co, H, W, dtype=torch.float64)
+    gain = 1.0 / math.sqrt(ci * 9)
+    wr = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    xs = x * s.view(B, ci, 1, 1) if scaled else x
+    yr = F.conv2d(F.pad(xs, [1] * 4, mode="reflect") if refl else xs, wr * gain, padding=0 if refl else 1)
+    if scaled:
+        yr = yr * d.view(B, co, 1, 1)
+    (gw_ref,) = torch.autograd.grad(yr, wr, gy)
+    g = ConvGeom(3, 3, 1, 1, refl)
+    xd, gyd = dev(x.float(), True), dev(gy.float(), True)
+    sd = dev(s.float()) if scaled else None
+    dd = dev(d.float()) if scaled else None
+    p = _lib.ConvParams(B, H, W, ci, H, W, co, H, W, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(refl), 0, 0.2, 1.0, 1.0, 0, gain)
+    assert _lib.load().ideas_b3_wino_wgrad_supported(C.byref(p)) == 1
+    math0, ww0 = CV.MATH, CV.B3_WINO_WGRAD
+    CV.MATH = _lib.F32_B3
+    try:
+        CV.B3_WINO_WGRAD = True
+        gw = CV.conv_wgrad_raw(gyd, xd, g, (co, ci, 3, 3), gain, lin=sd, lout=dd)
+        acc = torch.full((co, ci, 3, 3), 2.0, device="cuda").contiguous(memory_format=CL)
+        assert CV.conv_wgrad_raw(gyd, xd, g, (co, ci, 3, 3), gain, lin=sd, lout=dd, out=acc) is acc
+        CV.B3_WINO_WGRAD = False
+        gw_direct = CV.conv_wgrad_raw(gyd, xd, g, (co, ci, 3, 3), gain, lin=sd, lout=dd)
+    finally:
+        CV.MATH, CV.B3_WINO_WGRAD = math0, ww0
+    assert rel_err(gw, gw_ref) < 2e-6, (case, rel_err(gw, gw_ref))            # f32 class (suite bound for gradients: 1e-4)
+    assert rel_err(gw_direct, gw_ref) < 2e-6
+    assert rel_err(gw, gw_direct) < 2e-6
+    assert rel_err(acc - 2.0, gw_ref) < 2e-6
+    for buf in CV._GU.values():
+        assert float(buf.abs().max()) == 0.0
 
 
 # --------------------------------------------------------------------------------------------- operand preparation from strided views
