@@ -67,10 +67,38 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(T* __restrict__ y, cons
 
 // ---------------- NHWC 4x4 blur, up = down = 1 ---------------------------------------------------
 // thread = (b, row-segment, ox, c4); window w[r][t] holds input rows iy0..iy0+3 at columns ix0..ix0+3
-template <typename V>
+// EPI: a fused elementwise stage on the blurred value before it is stored (ideas_blur_fused):
+//   EPI_ACT_BWD   y = (ref > 0 ? v : v * alpha) * scale, bias_grad[c] += sum y    -- blur^T followed by the leaky-ReLU backward
+//                                                                                   of the layer below (ref = its saved output)
+//   EPI_BIAS_ACT  y = lrelu(v + bias[c], alpha) * scale                           -- the blur of an upsampling conv + FusedLeakyReLU
+// Same operation order as bias_act.hip's act_one, so f32 results are bitwise those of blur -> fused_bias_act.
+enum { EPI_NONE = 0, EPI_ACT_BWD = 1, EPI_BIAS_ACT = 2 };
+struct FirEpi {
+    const void* ref;
+    const float* bias;
+    float* bgrad;
+    float alpha, scale;
+};
+__device__ __forceinline__ float epi_act(float v, float sel, float alpha, float scale) { return (sel > 0.f ? v : v * alpha) * scale; }
+
+// per-thread partial bias gradients -> LDS (one slot per channel) -> one global atomic per channel and block
+__device__ __forceinline__ void bgrad_flush(float* s_bg, float* __restrict__ bgrad, int C, bool active, int c0, const float* part, int n) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s_bg[c] = 0.f;
+    __syncthreads();
+    if (active)
+        for (int e = 0; e < n; ++e) atomicAdd(&s_bg[c0 + e], part[e]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float v = s_bg[c];
+        if (v != 0.f) atomicAdd(&bgrad[c], v);
+    }
+}
+
+template <typename V, int EPI>
 __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __restrict__ x,
-                                                  const float* __restrict__ fir, FirParams p) {
+                                                  const float* __restrict__ fir, FirParams p, FirEpi ep) {
     __shared__ float sk[16];
+    extern __shared__ float s_bg[];
     if (threadIdx.x < 16) {
         int t = threadIdx.x;
         int src = p.flip ? 15 - t : t;
@@ -81,8 +109,12 @@ __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __
     const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
     const int64_t total = (int64_t)p.B * segs * p.out_w * C4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int64_t r = i;
+    const bool active = i < total;
+    if (EPI != EPI_ACT_BWD && !active) return;
+    // EPI_ACT_BWD ends in block barriers (bgrad_flush), which every lane of every wave has to reach along the SAME path: threads
+    // past the end redo the last thread's work with their stores and their share of the bias gradient masked off
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t r = active ? i : total - 1;
     const int c4 = (int)(r % C4); r /= C4;
     const int ox = (int)(r % p.out_w); r /= p.out_w;
     const int seg = (int)(r % segs);
@@ -116,6 +148,9 @@ __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __
     load_row(iy0 + 1, w[1]);
     load_row(iy0 + 2, w[2]);
     V* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    const V* rb = reinterpret_cast<const V*>(ep.ref) + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    float4 bb = zero;
+    if (EPI == EPI_BIAS_ACT) bb = *reinterpret_cast<const float4*>(ep.bias + 4 * c4);
     auto emit = [&](int oy, const float4 (&r0)[4], const float4 (&r1)[4], const float4 (&r2)[4], const float4 (&r3)[4]) {
         float4 acc = zero;
 #pragma unroll
@@ -125,6 +160,20 @@ __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __
             acc.y += r0[t].y * k0 + r1[t].y * k1 + r2[t].y * k2 + r3[t].y * k3;
             acc.z += r0[t].z * k0 + r1[t].z * k1 + r2[t].z * k2 + r3[t].z * k3;
             acc.w += r0[t].w * k0 + r1[t].w * k1 + r2[t].w * k2 + r3[t].w * k3;
+        }
+        if (EPI == EPI_ACT_BWD) {
+            const float4 rf = to_f4(rb[(int64_t)oy * p.out_w * C4]);
+            if (sizeof(V) != sizeof(float4)) acc = to_f4(from_f4<V>(acc));       // bf16: the unfused path stores the blur first
+            acc = make_float4(epi_act(acc.x, rf.x, ep.alpha, ep.scale), epi_act(acc.y, rf.y, ep.alpha, ep.scale),
+                              epi_act(acc.z, rf.z, ep.alpha, ep.scale), epi_act(acc.w, rf.w, ep.alpha, ep.scale));
+            bsum.x += acc.x; bsum.y += acc.y; bsum.z += acc.z; bsum.w += acc.w;
+            if (!active) return;
+        }
+        if (EPI == EPI_BIAS_ACT) {
+            if (sizeof(V) != sizeof(float4)) acc = to_f4(from_f4<V>(acc));
+            const float4 v = make_float4(acc.x + bb.x, acc.y + bb.y, acc.z + bb.z, acc.w + bb.w);
+            acc = make_float4(epi_act(v.x, v.x, ep.alpha, ep.scale), epi_act(v.y, v.y, ep.alpha, ep.scale),
+                              epi_act(v.z, v.z, ep.alpha, ep.scale), epi_act(v.w, v.w, ep.alpha, ep.scale));
         }
         yb[(int64_t)oy * p.out_w * C4] = from_f4<V>(acc);
     };
@@ -143,6 +192,10 @@ __global__ __launch_bounds__(256) void blur4_nhwc(V* __restrict__ y, const V* __
     if (oy < oy1) {
         load_row(oy - p.pad_y0 + 3, w[3]);
         emit(oy, w[0], w[1], w[2], w[3]);
+    }
+    if (EPI == EPI_ACT_BWD) {
+        const float part[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+        bgrad_flush(s_bg, ep.bgrad, p.C, active, 4 * c4, part, 4);
     }
 }
 
@@ -325,9 +378,11 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(ideas_pk_bf16(f[0], f[1]), ideas_pk_bf16(f[2], f[3]), ideas_pk_bf16(f[4], f[5]), ideas_pk_bf16(f[6], f[7]));
 }
 
+template <int EPI>
 __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const uint4* __restrict__ x,
-                                                    const float* __restrict__ fir, FirParams p) {
+                                                    const float* __restrict__ fir, FirParams p, FirEpi ep) {
     __shared__ float sk[16];
+    extern __shared__ float s_bg[];
     if (threadIdx.x < 16) {
         const int t = threadIdx.x;
         sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
@@ -347,8 +402,10 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
     const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
     const int64_t total = (int64_t)p.B * segs * p.out_w * C8;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int64_t r = i;
+    const bool active = i < total;
+    if (EPI != EPI_ACT_BWD && !active) return;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t r = active ? i : total - 1;      // (see blur4_nhwc: one path to the barriers of bgrad_flush)
     const int c8 = (int)(r % C8); r /= C8;
     const int ox = (int)(r % p.out_w); r /= p.out_w;
     const int seg = (int)(r % segs);
@@ -358,6 +415,31 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
     const int ix0 = ox - p.pad_x0;
     const uint4* xb = x + (int64_t)b * p.in_h * p.in_w * C8 + c8;
     uint4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C8 + c8;
+    const uint4* rb = reinterpret_cast<const uint4*>(ep.ref) + (((int64_t)b * p.out_h) * p.out_w + ox) * C8 + c8;
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[e] = ep.bias[8 * c8 + e];
+    }
+    // the fused stage of one output vector (the blur is rounded to bf16 first, as the unfused blur -> bias_act path stores it)
+    auto finish = [&](int oy, float (&o)[8]) {
+        if (EPI != EPI_NONE) {
+            const uint4 q = pack8(o);
+            unpack8(q, o);
+        }
+        if (EPI == EPI_ACT_BWD) {
+            float rf[8];
+            unpack8(rb[(int64_t)oy * p.out_w * C8], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = epi_act(o[e], rf[e], ep.alpha, ep.scale); bsum[e] += o[e]; }
+            if (!active) return;
+        }
+        if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = o[e] + bb[e]; o[e] = epi_act(v, v, ep.alpha, ep.scale); }
+        }
+        yb[(int64_t)oy * p.out_w * C8] = pack8(o);
+    };
     unsigned colmask = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
@@ -391,8 +473,9 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
                     for (int e = 0; e < 8; ++e) acc[e] = fmaf(f[e], sk[4 * j + t], acc[e]);
                 }
             }
-            yb[(int64_t)oy * p.out_w * C8] = pack8(acc);
+            finish(oy, acc);
         }
+        if (EPI == EPI_ACT_BWD) bgrad_flush(s_bg, ep.bgrad, p.C, active, 8 * c8, bsum, 8);
         return;
     }
     auto hfilter = [&](const uint4 (&row)[4], F8& h) {
@@ -410,7 +493,7 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = a0.v[e] * kv[0] + a1.v[e] * kv[1] + a2.v[e] * kv[2] + a3.v[e] * kv[3];
-        yb[(int64_t)oy * p.out_w * C8] = pack8(o);
+        finish(oy, o);
     };
     F8 h0, h1, h2, h3, h4;
     {
@@ -436,6 +519,7 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
         hfilter(ra, h3);
         emit(oy, h0, h1, h2, h3);
     }
+    if (EPI == EPI_ACT_BWD) bgrad_flush(s_bg, ep.bgrad, p.C, active, 8 * c8, bsum, 8);
 }
 
 // ---------------- NCHW tiled blur, up = down = 1, k <= 4 -------------------------------------------
@@ -487,6 +571,54 @@ __global__ __launch_bounds__(256) void blur_nchw_tile(float* __restrict__ y, con
 
 }  // namespace
 
+// the unit-stride 4x4 NHWC blur (+ fused stage): shared by ideas_upfirdn2d (EPI_NONE) and ideas_blur_fused
+template <int EPI>
+static int launch_blur4(void* y, const void* x, const float* fir, FirParams p, FirEpi ep, int dtype, hipStream_t stream) {
+    // rows marched per thread: each segment re-reads 3 halo rows (19/16 vs 35/32 of the input); short images keep 16 so
+    // that enough threads exist (measured: 32 is +5 % at 256x256, -5 % at 64x64)
+    p.seg_rows = p.out_h >= 128 ? 32 : 16;
+    const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * p.out_w * (p.C / 4);
+    const int64_t grid = ideas_cdiv(total, 256);
+    if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const size_t lds = EPI == EPI_ACT_BWD ? (size_t)p.C * sizeof(float) : 0;
+    if (dtype == IDEAS_BF16 && p.C % 8 == 0) {
+        const int64_t total8 = (int64_t)p.B * segs * p.out_w * (p.C / 8);
+        hipLaunchKernelGGL(blur4_bf16x8<EPI>, dim3((unsigned)ideas_cdiv(total8, 256)), dim3(256), lds, stream, (uint4*)y,
+                           (const uint4*)x, fir, p, ep);
+    } else if (dtype == IDEAS_BF16)
+        hipLaunchKernelGGL((blur4_nhwc<ideas_bf16x4, EPI>), dim3((unsigned)grid), dim3(256), lds, stream, (ideas_bf16x4*)y,
+                           (const ideas_bf16x4*)x, fir, p, ep);
+    else
+        hipLaunchKernelGGL((blur4_nhwc<float4, EPI>), dim3((unsigned)grid), dim3(256), lds, stream, (float4*)y, (const float4*)x, fir,
+                           p, ep);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_blur_fused(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h, int out_w,
+                                int pad_x0, int pad_y0, float gain, int flip, int mode, const void* ref, const float* bias,
+                                float* bias_grad, float alpha, float scale, int dtype, void* stream_) {
+    if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
+    if (!y || !x || !fir) return IDEAS_E_NULL;
+    if (B <= 0 || C <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) return IDEAS_E_SHAPE;
+    if (C % 4 || C > 8192) return IDEAS_E_UNSUPPORTED;
+    if (!ideas_aligned16(x) || !ideas_aligned16(y)) return IDEAS_E_ALIGN;
+    FirParams p{B, C, in_h, in_w, out_h, out_w, 4, 4, 1, 1, 1, 1, pad_x0, pad_y0, gain, flip, 16};
+    FirEpi ep{ref, bias, bias_grad, alpha, scale};
+    hipStream_t stream = (hipStream_t)stream_;
+    if (mode == EPI_ACT_BWD) {
+        if (!ref || !bias_grad) return IDEAS_E_NULL;
+        if (!ideas_aligned16(ref)) return IDEAS_E_ALIGN;
+        return launch_blur4<EPI_ACT_BWD>(y, x, fir, p, ep, dtype, stream);
+    }
+    if (mode == EPI_BIAS_ACT) {
+        if (!bias) return IDEAS_E_NULL;
+        if (!ideas_aligned16(bias)) return IDEAS_E_ALIGN;
+        return launch_blur4<EPI_BIAS_ACT>(y, x, fir, p, ep, dtype, stream);
+    }
+    return IDEAS_E_UNSUPPORTED;
+}
+
 extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h,
                                int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                                int pad_y0, float gain, int flip, int layout, int dtype, void* stream_) {
@@ -501,23 +633,7 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
     FirParams p{B, C, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, gain, flip, 16};
     const bool unit = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1;
     if (unit && layout == IDEAS_NHWC && kh == 4 && kw == 4 && (C % 4 == 0) && ideas_aligned16(x) && ideas_aligned16(y)) {
-        // rows marched per thread: each segment re-reads 3 halo rows (19/16 vs 35/32 of the input); short images keep 16 so
-        // that enough threads exist (measured: 32 is +5 % at 256x256, -5 % at 64x64)
-        p.seg_rows = out_h >= 128 ? 32 : 16;
-        const int segs = (out_h + p.seg_rows - 1) / p.seg_rows;
-        const int64_t total = (int64_t)B * segs * out_w * (C / 4);
-        const int64_t grid = ideas_cdiv(total, 256);
-        if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
-        if (dtype == IDEAS_BF16 && C % 8 == 0) {
-            const int64_t total8 = (int64_t)B * segs * out_w * (C / 8);
-            hipLaunchKernelGGL(blur4_bf16x8, dim3((unsigned)ideas_cdiv(total8, 256)), dim3(256), 0, stream, (uint4*)y,
-                               (const uint4*)x, fir, p);
-        } else if (dtype == IDEAS_BF16)
-            hipLaunchKernelGGL(blur4_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
-                               (const ideas_bf16x4*)x, fir, p);
-        else
-            hipLaunchKernelGGL(blur4_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
-        return ideas_launch_status();
+        return launch_blur4<EPI_NONE>(y, x, fir, p, FirEpi{nullptr, nullptr, nullptr, 0.f, 1.f}, dtype, stream);
     }
     const bool vec4 = layout == IDEAS_NHWC && kh == 4 && kw == 4 && (C % 4 == 0) && ideas_aligned16(x) && ideas_aligned16(y);
     if (vec4 && up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2) {

@@ -59,7 +59,7 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input, reflect_pad: int = 0, act: Optional[FusedLeakyReLU] = None, post_gain: float = 1.0,
-                resid: Optional[torch.Tensor] = None, stride: Optional[int] = None):
+                resid: Optional[torch.Tensor] = None, stride: Optional[int] = None, post_blur=None):
         """``act``: the FusedLeakyReLU that follows in the ConvLayer — folded into the conv epilogue.
         ``post_gain``: extra scalar on the layer output (the residual blocks' 1/sqrt(2)), folded into the
         activation gain / conv gain.  ``resid``: residual branch added in the epilogue (no-grad passes only).
@@ -71,10 +71,12 @@ class EqualConv2d(nn.Module):
                 return self.forward(input, reflect_pad, act, post_gain, resid)
             finally:
                 self.stride = saved
+        if post_blur is not None and (act is None or self.bias is not None or resid is not None or stride is not None):
+            raise RuntimeError("post_blur rides on the fused conv + activation path")
         if act is not None and self.bias is None:
             return conv2d_bias_act(input, self.weight, act.bias, stride=self.stride, padding=pad, reflect=refl,
                                    gain=self.scale, negative_slope=act.negative_slope, scale=act.scale * post_gain,
-                                   resid=resid)
+                                   resid=resid, post_blur=post_blur)
         if act is None:
             if self.bias is not None and post_gain != 1.0:
                 raise RuntimeError("post_gain with a conv bias is not used on this path")

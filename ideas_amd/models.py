@@ -24,6 +24,7 @@ from .op import FusedLeakyReLU, conv2d, conv_transpose2d, upfirdn2d
 from .precision import to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
+FUSE_BLUR_BACKWARD = True     # ResBlock: conv1 + conv2's Blur as one Function whose backward is one kernel (A/B switch for tools / tests)
 
 
 class EqualConvTranspose2d(nn.Module):
@@ -93,13 +94,14 @@ class ConvLayer(nn.Sequential):
         super().__init__(*mods)
         self.padding = conv_pad
 
-    def forward(self, input, post_gain: float = 1.0, resid=None):
+    def forward(self, input, post_gain: float = 1.0, resid=None, post_blur=None, skip_blur: bool = False):
         """``post_gain`` scales the layer output (folded into the conv / activation gain — every op after the conv is
         linear or the scaled leaky-ReLU, so the fold is exact up to rounding); ``resid`` is added in the last conv's
-        epilogue (no-grad passes only)."""
+        epilogue (no-grad passes only).  ``post_blur`` (a Blur module): apply the NEXT layer's blur behind this layer's conv +
+        activation (that layer is then called with ``skip_blur``) — same values, but the pair shares one backward kernel."""
         x = input
         mods = list(self)
-        i = 0
+        i = 1 if (skip_blur and isinstance(mods[0], Blur)) else 0
         while i < len(mods):
             m = mods[i]
             refl = 0
@@ -134,7 +136,12 @@ class ConvLayer(nn.Sequential):
                 nxt = i + (2 if act is not None else 1)
                 if nxt < len(mods) and post_gain != 1.0:
                     raise RuntimeError("post_gain needs the conv (+activation) to end the layer")
-                x = m(x, reflect_pad=refl, act=act, post_gain=post_gain, resid=resid)
+                pb = None
+                if post_blur is not None:
+                    if act is None or nxt < len(mods):
+                        raise RuntimeError("post_blur needs a layer ending in conv + FusedLeakyReLU")
+                    pb = (post_blur.kernel, post_blur.pad)
+                x = m(x, reflect_pad=refl, act=act, post_gain=post_gain, resid=resid, post_blur=pb)
                 i = nxt
                 continue
             if isinstance(m, EqualConvTranspose2d):
@@ -192,6 +199,11 @@ class ResBlock(nn.Module):
             self.skip = None
 
     def forward(self, input):
+        if FUSE_BLUR_BACKWARD and torch.is_grad_enabled() and isinstance(self.conv2[0], Blur) and isinstance(self.conv1[-1], FusedLeakyReLU):
+            # downsampling block under autograd: conv1 also applies conv2's blur, so that the backward of the pair is one kernel
+            # (blur adjoint + leaky-ReLU mask + bias gradient, op.conv._ConvBiasActBlur)
+            blur = self.conv2[0]
+            return _res_merge(self, lambda x: self.conv1(x, post_blur=blur), lambda h, **kw: self.conv2(h, skip_blur=True, **kw), input)
         return _res_merge(self, self.conv1, self.conv2, input)
 
 

@@ -554,14 +554,66 @@ class _ConvBiasAct(Function):
         return gx, gw, (gb if (ctx.needs_input_grad[2] and tgt is None) else None), None, None, None, None
 
 
+class _ConvBiasActBlur(Function):
+    """upfirdn2d(lrelu(gain * conv(x, w) + b) * act_gain, fir, pad): conv1 of a downsampling ResBlock together with the Blur that
+    opens its conv2 (models.py:185-187, 69).  Forward = the two kernels of the unfused chain (bitwise the same values).  Backward of
+    a plain pass: ONE kernel takes the blur's adjoint, applies the leaky-ReLU mask of the saved activation and reduces the bias
+    gradient (ideas_blur_fused) -- the gradient of the blurred tensor is never written back and re-read; when a graph is being
+    built (R1's double backward) the backward is composed of the differentiable Functions instead."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, g: ConvGeom, gain: float, slope: float, act_gain: float, fir, pad2):
+        from .upfirdn2d import blur_geometry, upfirdn2d_raw
+        x = _nhwc(x)
+        y1 = conv_fwd_raw(x, w, g, gain, bias=b.contiguous(), act=True, act_gain=act_gain, alpha=slope)
+        pad4, out_hw, g_pad = blur_geometry((y1.shape[2], y1.shape[3]), fir, pad2)
+        yb = upfirdn2d_raw(y1, fir, (1, 1), (1, 1), pad4, out_hw, flip=True)
+        ctx.g, ctx.gain, ctx.slope, ctx.act_gain = g, gain, slope, act_gain
+        ctx.pad4, ctx.g_pad, ctx.out_hw = pad4, g_pad, out_hw
+        ctx.bias_ref = b
+        ctx.save_for_backward(x, w, y1, fir)
+        return yb
+
+    @staticmethod
+    def backward(ctx, gyb):
+        from .fused_act import FusedLeakyReLUFunctionBackward, bias_sink
+        from .upfirdn2d import BLUR_ACT_BWD, UpFirDn2dBackward, blur_fused_ok, blur_fused_raw
+        x, w, y1, fir = ctx.saved_tensors
+        need_b = ctx.needs_input_grad[2]
+        gb = None
+        if torch.is_grad_enabled() or not blur_fused_ok(y1, fir):
+            g1 = UpFirDn2dBackward.apply(gyb, fir, (1, 1), (1, 1), ctx.pad4, ctx.g_pad, tuple(y1.shape), ctx.out_hw)
+            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(g1, y1, ctx.slope, ctx.act_gain, True)
+        else:
+            tgt = bias_sink(ctx.bias_ref) if need_b else None
+            if tgt is None:
+                gb = torch.zeros(y1.shape[1], device=y1.device, dtype=torch.float32)
+            g_pre = blur_fused_raw(_nhwc(gyb), fir, ctx.g_pad, (y1.shape[2], y1.shape[3]), False, BLUR_ACT_BWD, ref=y1,
+                                   bias_grad=tgt if tgt is not None else gb, alpha=ctx.slope, scale=ctx.act_gain)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(g_pre, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(w, g_pre, x, ctx.g, ctx.gain)
+        return gx, gw, (gb if need_b else None), None, None, None, None, None, None
+
+
 def conv2d_bias_act(input: torch.Tensor, weight: torch.Tensor, act_bias: torch.Tensor, stride: int = 1, padding: int = 0,
                     reflect: bool = False, gain: float = 1.0, negative_slope: float = 0.2,
-                    scale: float = 2 ** 0.5, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    scale: float = 2 ** 0.5, resid: Optional[torch.Tensor] = None, post_blur=None) -> torch.Tensor:
     """``fused_leaky_relu(gain * conv2d(input, weight), act_bias, negative_slope, scale)`` in one kernel.
-    ``resid`` (inference only): the residual branch, added in the same epilogue."""
+    ``resid`` (inference only): the residual branch, added in the same epilogue.
+    ``post_blur = (fir, (pad0, pad1))``: also apply ``upfirdn2d(., fir, pad=pad)`` to the result (the Blur of the next, downsampling,
+    layer) so that the backward can fuse the blur's adjoint with the activation's (``_ConvBiasActBlur``)."""
     _lib.require_cuda(input, weight, act_bias)
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, padding, reflect)
     input = to_act(input)
+    if post_blur is not None:
+        if resid is not None:
+            raise RuntimeError("conv2d_bias_act: post_blur and resid are exclusive")
+        fir, pad2 = post_blur
+        return _ConvBiasActBlur.apply(input, weight, act_bias, g, float(gain), float(negative_slope), float(scale), fir,
+                                      (int(pad2[0]), int(pad2[1])))
     if resid is not None:
         resid = to_act(resid)
         if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or act_bias.requires_grad or resid.requires_grad):

@@ -28,7 +28,7 @@ from .conv import conv_dgrad_raw, conv_fwd_raw, conv_wgrad_raw, weight_grad, _nh
 from .conv_plan import ConvGeom, convT_out_size
 from . import conv_plan
 from . import scratch
-from .upfirdn2d import upfirdn2d
+from .upfirdn2d import blur_bias_act, upfirdn2d
 from .fused_act import fused_leaky_relu
 
 
@@ -287,6 +287,8 @@ def modulated_conv2d(x: torch.Tensor, weight: torch.Tensor, style: torch.Tensor,
         if fir is None:
             raise RuntimeError("modulated_conv2d(upsample=True) needs the blur FIR")
         p = (fir.shape[0] - 2) - (k - 1)
+        if act_bias is not None:          # blur + bias + leaky-ReLU in one pass over the upsampled tensor
+            return blur_bias_act(y, fir, ((p + 1) // 2 + 1, p // 2 + 1), act_bias, negative_slope, act_scale)
         y = upfirdn2d(y, fir, pad=((p + 1) // 2 + 1, p // 2 + 1))
     if act_bias is not None:
         y = fused_leaky_relu(y, act_bias, negative_slope, act_scale)

@@ -45,6 +45,88 @@ def upfirdn2d_raw(x: torch.Tensor, fir: torch.Tensor, up: Tuple[int, int], down:
     return y
 
 
+BLUR_ACT_BWD, BLUR_BIAS_ACT = 1, 2
+
+
+def blur_fused_ok(x: torch.Tensor, fir: torch.Tensor) -> bool:
+    """Geometry the fused blur kernels take: channels_last 4-D tensor, C % 4 == 0, 4x4 FIR."""
+    return (x.dim() == 4 and x.is_cuda and x.shape[1] % 4 == 0 and tuple(fir.shape) == (4, 4)
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def blur_fused_raw(x: torch.Tensor, fir: torch.Tensor, pad: Tuple[int, int, int, int], out_hw: Tuple[int, int], flip: bool,
+                   mode: int, ref=None, bias=None, bias_grad=None, alpha: float = 0.2, scale: float = 1.0) -> torch.Tensor:
+    """One launch of ``ideas_blur_fused``: the 4x4 blur with the leaky-ReLU backward of the layer below (``BLUR_ACT_BWD``:
+    ``ref`` = its saved output, ``bias_grad`` f32 [C] accumulated into) or with bias + leaky-ReLU (``BLUR_BIAS_ACT``) in its store."""
+    _lib.require_cuda(x, fir, ref, bias, bias_grad)
+    b, c, h, w = x.shape
+    oh, ow = out_hw
+    x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+    if ref is not None:
+        if tuple(ref.shape) != (b, c, oh, ow):
+            raise RuntimeError("blur_fused: ref shape mismatch")
+        if ref.dtype != x.dtype:
+            x = x.to(ref.dtype)
+        ref = ref if ref.is_contiguous(memory_format=torch.channels_last) else ref.contiguous(memory_format=torch.channels_last)
+    if bias is not None:
+        bias = bias.contiguous().to(torch.float32)
+    y = torch.empty((b, c, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    rc = _lib.load().ideas_blur_fused(_lib.ptr(y), _lib.ptr(x), _lib.ptr(fir.contiguous().to(torch.float32)), b, c, h, w, oh, ow,
+                                      pad[0], pad[2], 1.0, int(flip), mode, _lib.ptr(ref), _lib.ptr(bias), _lib.ptr(bias_grad),
+                                      float(alpha), float(scale), _lib.act_dtype(x), _lib.stream_ptr())
+    _lib.check(rc, "ideas_blur_fused")
+    return y
+
+
+def blur_geometry(in_hw: Tuple[int, int], fir: torch.Tensor, pad2: Tuple[int, int]):
+    """(pad4, out_hw, g_pad4) of the unit-stride blur ``upfirdn2d(x, fir, pad=pad2)`` (upfirdn2d.py:95-114)."""
+    kh, kw = fir.shape
+    p0, p1 = pad2
+    oh, ow = in_hw[0] + p0 + p1 - kh + 1, in_hw[1] + p0 + p1 - kw + 1
+    g_pad = (kw - p0 - 1, in_hw[1] - ow + p0, kh - p0 - 1, in_hw[0] - oh + p0)
+    return (p0, p1, p0, p1), (oh, ow), g_pad
+
+
+class _BlurBiasAct(Function):
+    """fused_leaky_relu(upfirdn2d(x, fir, pad), bias, slope, scale) in one pass (the tail of an upsampling StyledConv,
+    stylegan2/model.py:258-261 + 374-375).  Backward: leaky-ReLU backward (+ bias gradient) then the blur's adjoint — composed of
+    the differentiable Functions when a graph is being built, raw kernels with the bias gradient sunk into bias.grad otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, fir, pad2, bias, slope: float, scale: float):
+        pad4, out_hw, g_pad = blur_geometry((x.shape[2], x.shape[3]), fir, pad2)
+        out = blur_fused_raw(x, fir, pad4, out_hw, True, BLUR_BIAS_ACT, bias=bias, alpha=slope, scale=scale)
+        ctx.pad4, ctx.g_pad, ctx.in_size, ctx.out_hw, ctx.slope, ctx.scale = pad4, g_pad, tuple(x.shape), out_hw, slope, scale
+        ctx.bias_ref = bias
+        ctx.save_for_backward(out, fir)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_act import FusedLeakyReLUFunctionBackward, bias_act_raw, bias_sink
+        out, fir = ctx.saved_tensors
+        one = (1, 1)
+        tgt = bias_sink(ctx.bias_ref) if ctx.needs_input_grad[3] else None
+        if tgt is not None:
+            g_pre, gb = bias_act_raw(gy, None, out, 1, ctx.slope, ctx.scale, bias_grad_into=tgt)
+        else:
+            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(gy, out, ctx.slope, ctx.scale, True)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = UpFirDn2dBackward.apply(g_pre, fir, one, one, ctx.pad4, ctx.g_pad, ctx.in_size, ctx.out_hw)
+        return gx, None, None, (gb if (ctx.needs_input_grad[3] and tgt is None) else None), None, None
+
+
+def blur_bias_act(x: torch.Tensor, fir: torch.Tensor, pad, bias: torch.Tensor, negative_slope: float = 0.2,
+                  scale: float = 2 ** 0.5) -> torch.Tensor:
+    """``fused_leaky_relu(upfirdn2d(x, fir, pad=pad), bias, negative_slope, scale)`` without the intermediate tensor."""
+    _lib.require_cuda(x, fir, bias)
+    if not blur_fused_ok(x, fir):
+        from .fused_act import fused_leaky_relu
+        return fused_leaky_relu(upfirdn2d(x, fir, pad=pad), bias, negative_slope, scale)
+    return _BlurBiasAct.apply(x, fir, (pad[0], pad[1]), bias, float(negative_slope), float(scale))
+
+
 class UpFirDn2dBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, kernel, up, down, pad, g_pad, in_size, out_size):

@@ -86,6 +86,22 @@ int ideas_upfirdn2d(void* y, const void* x, const float* fir,
                     int pad_x0, int pad_y0, float gain, int flip,
                     int layout, int dtype, void* stream);
 
+/* The 4x4 NHWC blur (up = down = 1; C % 4 == 0) with the elementwise pass that always follows it on the IDEAS path folded into
+ * its store, so the blurred tensor is never written and read back:
+ *   mode 1 (IDEAS_BLUR_ACT_BWD):  y = (ref > 0 ? v : v*alpha) * scale,  bias_grad[c] += sum over (b,h,w) of y
+ *        v = the blur of x.  The gradient of a downsampling ConvLayer's Blur (models.py:69, upfirdn2d.py:19-45) followed by the
+ *        leaky-ReLU backward of the conv layer below it (fused_act.py:20-47); `ref` = that layer's saved output, same shape and
+ *        dtype as y; `bias_grad` float[C], accumulated into (not zeroed here).
+ *   mode 2 (IDEAS_BLUR_BIAS_ACT): y = lrelu(v + bias[c], alpha) * scale
+ *        the Blur of an upsampling ModulatedConv2d followed by its FusedLeakyReLU (stylegan2/model.py:258-261, 371-377).
+ * Operation order is that of ideas_upfirdn2d -> ideas_fused_bias_act (for bf16 the blur is rounded to bf16 in between, as the
+ * two-kernel path stores it), so f32 results are bitwise the unfused ones.  `flip` / `gain` / pads as in ideas_upfirdn2d. */
+#define IDEAS_BLUR_ACT_BWD 1
+#define IDEAS_BLUR_BIAS_ACT 2
+int ideas_blur_fused(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h, int out_w,
+                     int pad_x0, int pad_y0, float gain, int flip, int mode, const void* ref, const float* bias,
+                     float* bias_grad, float alpha, float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32), NHWC.
  * Replaces the cuDNN calls behind F.conv2d / F.conv_transpose2d (stylegan2/model.py:115-121,258,273;

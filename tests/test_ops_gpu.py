@@ -478,6 +478,73 @@ def test_winograd_full_size_properties():
         CV.MATH = math0
 
 
+# --------------------------------------------------------------------------------------------- blur with a fused elementwise stage
+@pytest.mark.parametrize("shape,pad", [((2, 8, 33, 31), (2, 2)), ((3, 64, 16, 16), (2, 2)), ((2, 12, 9, 20), (1, 1)), ((1, 128, 65, 65), (2, 2))])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_blur_fused_stages_equal_the_two_kernel_chain(shape, pad, bf16):
+    """ideas_blur_fused: blur^T + leaky-ReLU backward + bias gradient (the backward of conv+act -> Blur in a downsampling
+    ResBlock) and blur + bias + leaky-ReLU (the tail of an upsampling StyledConv) against upfirdn2d -> fused_bias_act: the stored
+    tensors are BITWISE equal in both precisions (same operation order; bf16 rounds the blur in between like the two-kernel chain),
+    the bias gradient agrees to summation order."""
+    from ideas_amd.model import make_kernel
+    import importlib
+    U = importlib.import_module("ideas_amd.op.upfirdn2d")       # (ideas_amd.op.upfirdn2d the attribute is the function)
+    from ideas_amd.op.fused_act import bias_act_raw
+    B, C, H, W = shape
+    dt = torch.bfloat16 if bf16 else torch.float32
+    torch.manual_seed(sum(shape))
+    fir = make_kernel((1, 3, 3, 1)).cuda()
+    x = torch.randn(B, C, H, W, device="cuda").to(dt).contiguous(memory_format=CL)
+    bias = torch.randn(C, device="cuda")
+    pad4, out_hw, g_pad = U.blur_geometry((H, W), fir, pad)
+    # forward stage
+    want = bias_act_raw(U.upfirdn2d_raw(x, fir, (1, 1), (1, 1), pad4, out_hw, flip=True), bias, None, 0, 0.2, 2 ** 0.5)
+    got = U.blur_fused_raw(x, fir, pad4, out_hw, True, U.BLUR_BIAS_ACT, bias=bias, alpha=0.2, scale=2 ** 0.5)
+    assert torch.equal(got, want)
+    # backward stage: g is the gradient of the blurred tensor, y1 the saved activation below the blur
+    g = torch.randn(B, C, out_hw[0], out_hw[1], device="cuda").to(dt).contiguous(memory_format=CL)
+    y1 = torch.randn(B, C, H, W, device="cuda").to(dt).contiguous(memory_format=CL)
+    gin = U.upfirdn2d_raw(g, fir, (1, 1), (1, 1), g_pad, (H, W), flip=False)
+    want, want_bg = bias_act_raw(gin, None, y1, 1, 0.2, 2 ** 0.5, want_bias_grad=True)
+    bg = torch.full((C,), 3.0, device="cuda")
+    got = U.blur_fused_raw(g, fir, g_pad, (H, W), False, U.BLUR_ACT_BWD, ref=y1, bias_grad=bg, alpha=0.2, scale=2 ** 0.5)
+    assert torch.equal(got, want)
+    assert rel_err(bg - 3.0, want_bg) < (2e-3 if bf16 else 1e-5)      # bf16: the two-kernel chain sums the values before rounding them
+
+
+@pytest.mark.parametrize("reflect", [False, True])
+def test_downsampling_resblock_fused_backward_equals_unfused(reflect):
+    """models.ResBlock under autograd routes conv1 + conv2's Blur through _ConvBiasActBlur: outputs bitwise those of the module
+    chain, first-order gradients equal to atomics order, and the R1-style double backward (composed path) agrees too."""
+    from ideas_amd import models as M
+    torch.manual_seed(5)
+    blk = M.ResBlock(16, 32, downsample=True, padding="reflect" if reflect else "zero").cuda()
+    for prm in blk.parameters():
+        if prm.dim() == 1:
+            prm.data.normal_(0, 0.3)
+    x = torch.randn(2, 16, 20, 24, device="cuda").contiguous(memory_format=CL).requires_grad_(True)
+
+    def unfused(inp):
+        return M._res_merge(blk, blk.conv1, blk.conv2, inp)
+    y_f, y_u = blk(x), unfused(x)
+    assert torch.equal(y_f, y_u)
+    gy = torch.randn_like(y_f)
+    params = list(blk.parameters())
+    gf = torch.autograd.grad(y_f, [x] + params, gy)
+    gu = torch.autograd.grad(y_u, [x] + params, gy)
+    for a, b in zip(gf, gu):
+        assert rel_err(a, b) < 1e-5, (tuple(a.shape), rel_err(a, b))
+    # double backward: gradient penalty |dy/dx|^2 differentiated w.r.t. the parameters
+    def penalty(fn):
+        xx = x.detach().requires_grad_(True)
+        (gx,) = torch.autograd.grad(fn(xx).sum(), xx, create_graph=True)
+        return torch.autograd.grad(gx.pow(2).sum(), params, allow_unused=True)
+    for a, b in zip(penalty(blk), penalty(unfused)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert rel_err(a, b) < 1e-5
+
+
 # --------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_blur_and_bias_act_properties():
     """BASELINE sizes (B=32, 128 ch, 256x256): properties that need no reference at that size.
