@@ -161,6 +161,50 @@ def roofline_probe(device, batch: int, launches: int):
             "mfma_executed_frac": round(achieved * (2.0 / 3.0 if wino else 1.0) / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
+def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
+    """Second roofline entry: the weight-gradient kernel of the same G.layers.7.conv2 launch -- the kernel family
+    with the largest summed share of the step after the forward family -- timed with HIP events, accumulating into an existing
+    gradient buffer exactly as inside grad_sink.  Same algorithmic FLOPs and the same peak as the forward entry."""
+    from ideas_amd import _lib
+    from ideas_amd.op import conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    g = torch.Generator(device="cpu").manual_seed(8)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    x = torch.randn(batch, 128, 256, 256, generator=g).to(device).to(adt).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(batch, 128, 256, 256, generator=g).to(device).to(adt).contiguous(memory_format=torch.channels_last)
+    s = (torch.randn(batch, 128, generator=g) * 0.5 + 1).to(device)
+    d = (torch.rand(batch, 128, generator=g) + 0.5).to(device)
+    acc = torch.zeros(128, 128, 3, 3, device=device).contiguous(memory_format=torch.channels_last)
+    geom = ConvGeom(3, 3, 1, 1, False)
+    run = lambda: CV.conv_wgrad_raw(gy, x, geom, (128, 128, 3, 3), 0.03, lin=s, lout=d, out=acc)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    if bf16:
+        peak, kern = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_wgrad_kernel<2,2,2,2,true,false> (LDS-DMA tiles, ds_read_b64_tr_b16 transpose reads, one bf16 product per MFMA)"
+    elif CV.MATH == _lib.F32_B3:
+        wino = CV.B3_WINO_WGRAD
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        kern = ("conv_b3_wino_wgrad_kernel<2,2,2,2,true,false> + wino_wgrad_fold_kernel (Winograd-domain, 2/3 of the products; " if wino
+                else "conv_b3_wgrad_kernel<2,2,2,2,true,false> (") + "exact 3-way bf16 split of both operands, 6 bf16 MFMA products per f32 product)"
+    else:
+        peak, kern = PEAK_F32_MFMA_TFLOPS, "conv3x3_wino_wgrad_kernel / conv_wgrad_kernel (f32 MFMA)"
+    elem = 2 if bf16 else 4
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": None, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, split-K in XCD-banded "
+            "order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "algorithmic_bytes_per_launch": 2.0 * batch * 256 * 256 * 128 * elem}
+
+
 def _src_sha(files):
     import hashlib
     h = hashlib.sha256()
@@ -345,7 +389,8 @@ def main():
     bf16 = a.precision == "bf16"
     probe = roofline_probe_bf16 if bf16 else roofline_probe
     if a.roofline == "only":
-        print(json.dumps({"roofline": probe(device, a.batch, a.roofline_launches)}))
+        print(json.dumps({"roofline": probe(device, a.batch, a.roofline_launches),
+                          "roofline_wgrad": roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16)}))
         return
     from ideas_amd import precision
     precision.set_activation_dtype(a.precision)
@@ -432,6 +477,7 @@ def main():
         del trainer
         torch.cuda.empty_cache()
         out["roofline"] = probe(device, a.batch, a.roofline_launches)
+        out["roofline_wgrad"] = roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16)
     if a.cpu_baseline == "auto" and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_config1"] = cpu_baseline_config1()
