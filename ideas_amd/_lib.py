@@ -52,6 +52,7 @@ _PROTOS = {
     "ideas_fused_bias_act": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_float, C.c_int, _P]),
     "ideas_upfirdn2d": (C.c_int, [_P, _P, _P] + [C.c_int] * 14 + [C.c_float, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_fir_up2_add": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_int, _P]),
     "ideas_blur_fused": (C.c_int, [_P, _P, _P] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_int, _P, _P, _P, C.c_float, C.c_float,
                                    C.c_int, _P]),
     "ideas_conv_igemm": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),

@@ -271,9 +271,11 @@ __global__ __launch_bounds__(256) void fir4_down2_nhwc(V* __restrict__ y, const 
 // (a = 0, 1) sees the two taps k = k0(a), k0(a) + 2 with k0(a) = (pad0 - a) & 1, at inputs i + d(a), i + d(a) + 1,
 // d(a) = (a + k0(a) - pad0) / 2 -- so a 2 x 2 output block needs a 3 x 3 input neighbourhood.  A thread owns the output
 // column pair (2j, 2j + 1) of 4 channels and marches down block rows: 3 loads and 4 stores per block row.
+// `resid` (optional, same shape as y): y = fir(x) + resid -- the residual merge behind an upsampling skip, and (as the adjoint of
+// fir4_down2) the sum of the two input gradients of a downsampling ResBlock, without a separate add pass (ideas_fir_up2_add).
 template <typename V>
 __global__ __launch_bounds__(256) void fir4_up2_nhwc(V* __restrict__ y, const V* __restrict__ x, const float* __restrict__ fir,
-                                                     FirParams p) {
+                                                     FirParams p, const V* __restrict__ resid) {
     __shared__ float sk[16];
     if (threadIdx.x < 16) {
         const int t = threadIdx.x;
@@ -353,7 +355,13 @@ __global__ __launch_bounds__(256) void fir4_up2_nhwc(V* __restrict__ y, const V*
                 acc.y = t0.y * w00 + t1.y * w01 + b0.y * w10 + b1.y * w11;
                 acc.z = t0.z * w00 + t1.z * w01 + b0.z * w10 + b1.z * w11;
                 acc.w = t0.w * w00 + t1.w * w01 + b0.w * w10 + b1.w * w11;
-                y[(((int64_t)b * p.out_h + oy) * p.out_w + 2 * j + bb) * C4 + c4] = from_f4<V>(acc);
+                const int64_t yi = (((int64_t)b * p.out_h + oy) * p.out_w + 2 * j + bb) * C4 + c4;
+                if (resid) {
+                    if (sizeof(V) != sizeof(float4)) acc = to_f4(from_f4<V>(acc));     // bf16: the two-kernel chain stores the FIR first
+                    const float4 rv = to_f4(resid[yi]);
+                    acc = make_float4(acc.x + rv.x, acc.y + rv.y, acc.z + rv.z, acc.w + rv.w);
+                }
+                y[yi] = from_f4<V>(acc);
             }
         }
 #pragma unroll
@@ -619,9 +627,9 @@ extern "C" int ideas_blur_fused(void* y, const void* x, const float* fir, int B,
     return IDEAS_E_UNSUPPORTED;
 }
 
-extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h,
-                               int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
-                               int pad_y0, float gain, int flip, int layout, int dtype, void* stream_) {
+static int upfirdn2d_impl(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h,
+                          int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                          int pad_y0, float gain, int flip, int layout, int dtype, void* stream_, const void* resid) {
     if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (dtype == IDEAS_BF16 && layout != IDEAS_NHWC) return IDEAS_E_UNSUPPORTED;
     if (!y || !x || !fir) return IDEAS_E_NULL;
@@ -648,6 +656,7 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
             hipLaunchKernelGGL(fir4_down2_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
         return ideas_launch_status();
     }
+    if (resid && !(vec4 && up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1 && ideas_aligned16(resid))) return IDEAS_E_UNSUPPORTED;
     if (vec4 && up_x == 2 && up_y == 2 && down_x == 1 && down_y == 1) {
         const int bh = (out_h + 1) / 2, bw = (out_w + 1) / 2;
         p.seg_rows = bh >= 64 ? 16 : 8;
@@ -656,9 +665,10 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
         if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
         if (dtype == IDEAS_BF16)
             hipLaunchKernelGGL(fir4_up2_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
-                               (const ideas_bf16x4*)x, fir, p);
+                               (const ideas_bf16x4*)x, fir, p, (const ideas_bf16x4*)resid);
         else
-            hipLaunchKernelGGL(fir4_up2_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p);
+            hipLaunchKernelGGL(fir4_up2_nhwc<float4>, dim3((unsigned)grid), dim3(256), 0, stream, (float4*)y, (const float4*)x, fir, p,
+                               (const float4*)resid);
         return ideas_launch_status();
     }
     if (unit && layout == IDEAS_NCHW && kh <= 4 && kw <= 4) {
@@ -680,4 +690,18 @@ extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, 
         hipLaunchKernelGGL((upfirdn2d_generic<false, float>), dim3((unsigned)grid), dim3(256), 0, stream, (float*)y,
                            (const float*)x, fir, p);
     return ideas_launch_status();
+}
+
+extern "C" int ideas_upfirdn2d(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h,
+                               int out_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                               int pad_y0, float gain, int flip, int layout, int dtype, void* stream_) {
+    return upfirdn2d_impl(y, x, fir, B, C, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, gain, flip,
+                          layout, dtype, stream_, nullptr);
+}
+
+extern "C" int ideas_fir_up2_add(void* y, const void* x, const float* fir, const void* resid, int B, int C, int in_h, int in_w,
+                                 int out_h, int out_w, int pad_x0, int pad_y0, float gain, int flip, int dtype, void* stream_) {
+    if (!resid) return IDEAS_E_NULL;
+    return upfirdn2d_impl(y, x, fir, B, C, in_h, in_w, out_h, out_w, 4, 4, 2, 2, 1, 1, pad_x0, pad_y0, gain, flip, IDEAS_NHWC, dtype,
+                          stream_, resid);
 }

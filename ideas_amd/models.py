@@ -21,9 +21,12 @@ from torch import nn
 from .model import (CL, Blur, EqualConv2d, EqualLinear, ScaledLeakyReLU,
                     StyledConv_without_noise as StyledConv)
 from .op import FusedLeakyReLU, conv2d, conv_transpose2d, upfirdn2d
-from .precision import to_f32
+from .op.conv import fork_conv2d
+from .op.upfirdn2d import fork_down2, upfirdn2d_up2_add
+from .precision import to_act, to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
+FUSE_RESIDUAL_ADDS = True     # big residual blocks: block input forked by one autograd node (gradient sum / merge add ride in kernels)
 FUSE_BLUR_BACKWARD = True     # ResBlock: conv1 + conv2's Blur as one Function whose backward is one kernel (A/B switch for tools / tests)
 
 
@@ -161,12 +164,40 @@ def _res_merge(block, body, last, input):
     if not torch.is_grad_enabled():
         skip = block.skip(input, post_gain=_INV_SQRT2)
         return last(body(input), post_gain=_INV_SQRT2, resid=skip)
+    if FUSE_RESIDUAL_ADDS and torch.is_grad_enabled() and input.is_cuda:
+        y = _res_merge_forked(block, body, last, input)
+        if y is not None:
+            return y
     out = last(body(input), post_gain=_INV_SQRT2)
     if isinstance(block.skip[-1], EqualConv2d):
         # the skip branch ends in a bias-free linear conv (same-resolution and downsampling blocks): the merge add rides in
         # that conv's epilogue and differentiates trivially (d/d out = the incoming gradient)
         return block.skip(input, post_gain=_INV_SQRT2, resid=out)
     return out + block.skip(input, post_gain=_INV_SQRT2)      # upsampling skip ends in a blur
+
+
+def _res_merge_forked(block, body, last, input):
+    """The two big blocks' shapes with the block input forked by ONE autograd node, so that the sum of its two gradients rides in a
+    kernel that runs anyway instead of autograd's accumulation pass, and (upsampling) the merge add rides in the skip's FIR:
+      downsampling  skip = [Blur, 1x1 stride-2 conv]     -> (x, fir_down2(x)) = fork_down2;  backward: fir_up2(g_skip) + g_body
+      upsampling    skip = [1x1 stride-2 convT, Blur]    -> (x, conv1x1(x)) = fork_conv2d;  backward: dgrad(g_skip) + g_body in the
+                                                            epilogue; forward merge: fir_up2(conv1x1(x)) + body(x) in the FIR
+    Returns None for any other block (same-resolution skips are 16x16 tensors)."""
+    mods = list(block.skip)
+    if (len(mods) == 2 and isinstance(mods[0], Blur) and isinstance(mods[1], EqualConv2d) and mods[1].stride == 2
+            and mods[1].padding == 0 and tuple(mods[1].weight.shape[2:]) == (1, 1) and mods[1].bias is None
+            and input.shape[1] % 4 == 0):
+        xa, h = fork_down2(to_act(input), mods[0].kernel, mods[0].pad)
+        out = last(body(xa), post_gain=_INV_SQRT2)
+        return mods[1](h, post_gain=_INV_SQRT2, resid=out, stride=1)
+    if (len(mods) == 2 and isinstance(mods[0], EqualConvTranspose2d) and isinstance(mods[1], Blur) and mods[0].stride == 2
+            and mods[0].bias is None and tuple(mods[0].weight.shape[2:]) == (1, 1) and input.shape[1] % 4 == 0
+            and mods[0].weight.shape[1] % 4 == 0):
+        m, blur = mods
+        xa, h = fork_conv2d(input, m.weight.transpose(0, 1), gain=m.scale * _INV_SQRT2)
+        out = last(body(xa), post_gain=_INV_SQRT2)
+        return upfirdn2d_up2_add(h, blur.kernel, (blur.pad[0], blur.pad[1] - 1), out)
+    return None
 
 
 class StyledResBlock(nn.Module):

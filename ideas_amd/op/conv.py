@@ -219,9 +219,20 @@ def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None,
     return y
 
 
-def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=None, lout=None):
-    """Input gradient of the conv geometry (also: forward of the matching transposed conv)."""
+def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=None, lout=None, resid=None):
+    """Input gradient of the conv geometry (also: forward of the matching transposed conv).  ``resid`` (the result's shape): added
+    in the kernel epilogue -- single-launch geometries only (stride 1, no mirror padding), e.g. the 1x1 skip convs."""
     gy = _nhwc(gy)
+    if resid is not None:
+        if g.reflect or g.stride != 1:
+            raise RuntimeError("conv_dgrad_raw(resid=...) needs a single-launch geometry")
+        launches, need_zero = plan_dgrad(gy.shape, w, g, in_hw)
+        if len(launches) != 1 or need_zero:
+            raise RuntimeError("conv_dgrad_raw(resid=...) needs a single-launch geometry")
+        gx = torch.empty((gy.shape[0], w.shape[1], in_hw[0], in_hw[1]), device=gy.device, dtype=gy.dtype, memory_format=CL)
+        resid = _nhwc(resid)
+        launch_fwd(gx, gy, launches[0], gain, lin, lout, resid=resid if resid.dtype == gy.dtype else resid.to(gy.dtype), resid_gain=1.0)
+        return gx
     if g.reflect:
         # gradient w.r.t. the reflect-padded input, then fold the mirrored border back
         gp = ConvGeom(g.kh, g.kw, g.stride, 0, False)
@@ -504,6 +515,44 @@ class _ConvWgrad(Function):
         if ctx.needs_input_grad[1]:
             g_x = _ConvDgrad.apply(gy, ggw, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
         return g_gy, g_x, None, None, None
+
+
+class _ForkConv(Function):
+    """x -> (x, gain * conv(x, w)) for a stride-1 conv without mirror padding (the 1x1 conv an upsampling skip branch starts with,
+    models.py:170-172 after the reordering of ConvLayer.forward): owning the fork lets the backward add the gradient of the other
+    use of x in the input-gradient kernel's epilogue instead of autograd's separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x, w, g: ConvGeom, gain: float):
+        ctx.g, ctx.gain = g, gain
+        x = _nhwc(x)
+        ctx.save_for_backward(x, w)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), conv_fwd_raw(x, w, g, gain)
+
+    @staticmethod
+    def backward(ctx, ga, gh):
+        x, w = ctx.saved_tensors
+        if gh is None:
+            return ga, None, None, None
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if ga is not None and not torch.is_grad_enabled() and ga.is_contiguous(memory_format=CL) and ga.dtype == x.dtype:
+                gx = conv_dgrad_raw(_nhwc(gh), w, ctx.g, (x.shape[2], x.shape[3]), ctx.gain, resid=ga)
+            else:
+                gx = _ConvDgrad.apply(gh, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
+                gx = gx if ga is None else gx + ga
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(w, gh, x, ctx.g, ctx.gain)
+        return gx, gw, None, None
+
+
+def fork_conv2d(input: torch.Tensor, weight: torch.Tensor, padding: int = 0, gain: float = 1.0):
+    """``(input, gain * F.conv2d(input, weight, padding=padding))`` with the gradient sum of the two uses of ``input`` fused into
+    the conv's input-gradient kernel."""
+    _lib.require_cuda(input, weight)
+    g = ConvGeom(weight.shape[2], weight.shape[3], 1, padding, False)
+    return _ForkConv.apply(to_act(input), weight, g, float(gain))
 
 
 def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,

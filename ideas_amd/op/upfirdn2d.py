@@ -127,6 +127,93 @@ def blur_bias_act(x: torch.Tensor, fir: torch.Tensor, pad, bias: torch.Tensor, n
     return _BlurBiasAct.apply(x, fir, (pad[0], pad[1]), bias, float(negative_slope), float(scale))
 
 
+def _geometry(in_hw, fir, up: int, down: int, pad2):
+    """(pad4, out_hw, g_pad4) of ``upfirdn2d(x, fir, up, down, pad=pad2)`` (upfirdn2d.py:95-114)."""
+    kh, kw = fir.shape
+    p0, p1 = pad2
+    oh = (in_hw[0] * up + p0 + p1 - kh) // down + 1
+    ow = (in_hw[1] * up + p0 + p1 - kw) // down + 1
+    g_pad = (kw - p0 - 1, in_hw[1] * up - ow * down + p0 - up + 1, kh - p0 - 1, in_hw[0] * up - oh * down + p0 - up + 1)
+    return (p0, p1, p0, p1), (oh, ow), g_pad
+
+
+def fir_up2_add_raw(x: torch.Tensor, fir: torch.Tensor, pad: Tuple[int, int, int, int], out_hw: Tuple[int, int], flip: bool,
+                    resid: torch.Tensor) -> torch.Tensor:
+    """One launch of ``ideas_fir_up2_add``: the zero-stuffing FIR (up = 2) plus ``resid`` (the output's shape)."""
+    _lib.require_cuda(x, fir, resid)
+    b, c, h, w = x.shape
+    if tuple(resid.shape) != (b, c, out_hw[0], out_hw[1]):
+        raise RuntimeError("fir_up2_add: resid shape mismatch")
+    if resid.dtype != x.dtype:
+        resid = resid.to(x.dtype)
+    cl = torch.channels_last
+    x = x if x.is_contiguous(memory_format=cl) else x.contiguous(memory_format=cl)
+    resid = resid if resid.is_contiguous(memory_format=cl) else resid.contiguous(memory_format=cl)
+    y = torch.empty((b, c, out_hw[0], out_hw[1]), device=x.device, dtype=x.dtype, memory_format=cl)
+    rc = _lib.load().ideas_fir_up2_add(_lib.ptr(y), _lib.ptr(x), _lib.ptr(fir.contiguous().to(torch.float32)), _lib.ptr(resid), b, c, h, w,
+                                       out_hw[0], out_hw[1], pad[0], pad[2], 1.0, int(flip), _lib.act_dtype(x), _lib.stream_ptr())
+    _lib.check(rc, "ideas_fir_up2_add")
+    return y
+
+
+class _FirUp2Add(Function):
+    """upfirdn2d(x, fir, up=2, pad) + resid in one pass (the residual merge of an upsampling block, models.py:160-178)."""
+
+    @staticmethod
+    def forward(ctx, x, fir, pad2, resid):
+        pad4, out_hw, g_pad = _geometry((x.shape[2], x.shape[3]), fir, 2, 1, pad2)
+        ctx.pad4, ctx.g_pad, ctx.in_size, ctx.out_hw = pad4, g_pad, tuple(x.shape), out_hw
+        ctx.save_for_backward(fir)
+        return fir_up2_add_raw(x, fir, pad4, out_hw, True, resid)
+
+    @staticmethod
+    def backward(ctx, g):
+        (fir,) = ctx.saved_tensors
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = UpFirDn2dBackward.apply(g, fir, (2, 2), (1, 1), ctx.pad4, ctx.g_pad, ctx.in_size, ctx.out_hw)
+        return gx, None, None, (g if ctx.needs_input_grad[3] else None)
+
+
+def upfirdn2d_up2_add(x: torch.Tensor, fir: torch.Tensor, pad, resid: torch.Tensor) -> torch.Tensor:
+    """``upfirdn2d(x, fir, up=2, pad=pad) + resid`` without the intermediate tensor."""
+    if not (blur_fused_ok(x, fir) and resid.dim() == 4):
+        return upfirdn2d(x, fir, up=2, pad=pad) + resid
+    return _FirUp2Add.apply(x, fir, (pad[0], pad[1]), resid)
+
+
+class _ForkDown2(Function):
+    """x -> (x, upfirdn2d(x, fir, down=2, pad)): the input of a downsampling ResBlock handed to its body together with the
+    decimated tensor its skip branch starts from (models.py:189-191, 78-95).  Owning the fork lets the backward add the two
+    gradients inside the FIR's adjoint (ideas_fir_up2_add) instead of autograd's separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x, fir, pad2):
+        pad4, out_hw, g_pad = _geometry((x.shape[2], x.shape[3]), fir, 1, 2, pad2)
+        ctx.pad4, ctx.g_pad, ctx.in_size, ctx.out_hw = pad4, g_pad, tuple(x.shape), out_hw
+        ctx.save_for_backward(fir)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), upfirdn2d_raw(x, fir, (1, 1), (2, 2), pad4, out_hw, flip=True)
+
+    @staticmethod
+    def backward(ctx, ga, gh):
+        (fir,) = ctx.saved_tensors
+        if gh is None:
+            return ga, None, None
+        fused = (ga is not None and not torch.is_grad_enabled() and blur_fused_ok(gh, fir)
+                 and ga.is_contiguous(memory_format=torch.channels_last))
+        if fused:
+            return fir_up2_add_raw(gh, fir, ctx.g_pad, (ctx.in_size[2], ctx.in_size[3]), False, ga), None, None
+        gx = UpFirDn2dBackward.apply(gh, fir, (1, 1), (2, 2), ctx.pad4, ctx.g_pad, ctx.in_size, ctx.out_hw)
+        return (gx if ga is None else gx + ga), None, None
+
+
+def fork_down2(x: torch.Tensor, fir: torch.Tensor, pad):
+    """``(x, upfirdn2d(x, fir, down=2, pad=pad))`` with the gradient sum of the two uses fused into the FIR's adjoint."""
+    _lib.require_cuda(x, fir)
+    return _ForkDown2.apply(x, fir, (pad[0], pad[1]))
+
+
 class UpFirDn2dBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, kernel, up, down, pad, g_pad, in_size, out_size):

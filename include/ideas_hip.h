@@ -96,6 +96,13 @@ int ideas_upfirdn2d(void* y, const void* x, const float* fir,
  *        the Blur of an upsampling ModulatedConv2d followed by its FusedLeakyReLU (stylegan2/model.py:258-261, 371-377).
  * Operation order is that of ideas_upfirdn2d -> ideas_fused_bias_act (for bf16 the blur is rounded to bf16 in between, as the
  * two-kernel path stores it), so f32 results are bitwise the unfused ones.  `flip` / `gain` / pads as in ideas_upfirdn2d. */
+/* The zero-stuffing 4x4 NHWC FIR (up = 2, down = 1; C % 4 == 0) of ideas_upfirdn2d plus a tensor of the output's shape:
+ * y = fir(x) + resid.  Forward: the residual merge behind an upsampling skip branch (models.py:160-178: (conv2(...) + skip) with
+ * the skip ending in a Blur); backward: the sum of the two input gradients of a downsampling ResBlock, whose skip branch starts
+ * with the decimating FIR this kernel is the adjoint of.  Saves the separate add pass (3 tensor passes). */
+int ideas_fir_up2_add(void* y, const void* x, const float* fir, const void* resid, int B, int C, int in_h, int in_w, int out_h,
+                      int out_w, int pad_x0, int pad_y0, float gain, int flip, int dtype, void* stream);
+
 #define IDEAS_BLUR_ACT_BWD 1
 #define IDEAS_BLUR_BIAS_ACT 2
 int ideas_blur_fused(void* y, const void* x, const float* fir, int B, int C, int in_h, int in_w, int out_h, int out_w,

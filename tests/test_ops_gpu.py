@@ -545,6 +545,56 @@ def test_downsampling_resblock_fused_backward_equals_unfused(reflect):
             assert rel_err(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("kind", ["down", "down_reflect", "up"])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_forked_residual_blocks_equal_the_plain_autograd_graph(kind, bf16):
+    """models._res_merge_forked (block input forked by one autograd node: gradient sum inside ideas_fir_up2_add / the 1x1 input-
+    gradient epilogue, upsampling merge add inside the FIR) against the same block with FUSE_RESIDUAL_ADDS / FUSE_BLUR_BACKWARD off:
+    f32 outputs bitwise, first-order gradients to atomics order, double backward (composed path) as well."""
+    from ideas_amd import models as M
+    from ideas_amd import precision
+    torch.manual_seed(9)
+    precision.set_activation_dtype("bf16" if bf16 else "f32")
+    try:
+        if kind == "up":
+            blk = M.StyledResBlock(32, 16, 64, upsample=True).cuda()
+            style = torch.randn(2, 64, device="cuda")
+            fwd = lambda inp: blk(inp, style)
+            x = torch.randn(2, 32, 12, 10, device="cuda")
+        else:
+            blk = M.ResBlock(16, 32, downsample=True, padding="reflect" if kind == "down_reflect" else "zero").cuda()
+            fwd = blk
+            x = torch.randn(2, 16, 20, 24, device="cuda")
+        for prm in blk.parameters():
+            if prm.dim() == 1:
+                prm.data.normal_(0, 0.3)
+        x = x.contiguous(memory_format=CL).requires_grad_(True)
+        params = list(blk.parameters())
+        gy = None
+        res = {}
+        for flag in (True, False):
+            M.FUSE_RESIDUAL_ADDS = M.FUSE_BLUR_BACKWARD = flag
+            y = fwd(x)
+            gy = torch.randn_like(y) if gy is None else gy
+            g1 = torch.autograd.grad(y, [x] + params, gy, allow_unused=True)
+            xx = x.detach().requires_grad_(True)
+            (gx,) = torch.autograd.grad(fwd(xx).float().sum(), xx, create_graph=True)
+            g2 = torch.autograd.grad(gx.float().pow(2).sum(), params, allow_unused=True) if not bf16 and kind != "up" else ()
+            res[flag] = (y, g1, g2)
+    finally:
+        M.FUSE_RESIDUAL_ADDS = M.FUSE_BLUR_BACKWARD = True
+        precision.set_activation_dtype("f32")
+    if not bf16:
+        assert torch.equal(res[True][0], res[False][0])
+    tol = 3e-2 if bf16 else 1e-5
+    assert rel_err(res[True][0], res[False][0]) < tol
+    for grp in (1, 2):
+        for a, b in zip(res[True][grp], res[False][grp]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert rel_err(a, b) < tol, (grp, tuple(a.shape), rel_err(a, b))
+
+
 # --------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_blur_and_bias_act_properties():
     """BASELINE sizes (B=32, 128 ch, 256x256): properties that need no reference at that size.
