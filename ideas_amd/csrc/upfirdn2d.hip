@@ -530,6 +530,202 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
     if (EPI == EPI_ACT_BWD) bgrad_flush(s_bg, ep.bgrad, p.C, active, 8 * c8, bsum, 8);
 }
 
+// ---------------- bf16 NHWC decimating / zero-stuffing 4x4 FIRs, 8 channels (16 bytes) per thread ------------------------------
+// Same reason as blur4_bf16x8: with 2-byte elements the 4-channel kernels above move 8 bytes per lane and instruction and are
+// latency-bound (fir4_up2 / fir4_down2 on bf16: ~1.5 TB/s).  down2 keeps a window of four horizontally filtered rows (the FIR is an
+// outer product; checked on the device, a rank > 1 table takes the direct loop) and advances two input rows per output row; up2
+// keeps the 3 x 3 input neighbourhood of a 2 x 2 output block in registers (72 floats).
+__global__ __launch_bounds__(256) void fir4_down2_bf16x8(uint4* __restrict__ y, const uint4* __restrict__ x,
+                                                         const float* __restrict__ fir, FirParams p) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    float kh[4], kv[4];
+    float kmax = 0.f, res = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { kh[t] = sk[t]; kv[t] = sk[0] != 0.f ? sk[4 * t] / sk[0] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kmax = fmaxf(kmax, fabsf(sk[4 * j + t])); res = fmaxf(res, fabsf(sk[4 * j + t] - kv[j] * kh[t])); }
+    const bool sep = res <= 1e-6f * kmax;           // block-uniform
+    const int C8 = p.C >> 3;
+    const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * p.out_w * C8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int c8 = (int)(r % C8); r /= C8;
+    const int ox = (int)(r % p.out_w); r /= p.out_w;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int oy0 = seg * p.seg_rows;
+    const int oy1 = (oy0 + p.seg_rows < p.out_h) ? oy0 + p.seg_rows : p.out_h;
+    const int ix0 = 2 * ox - p.pad_x0;
+    const uint4* xb = x + (int64_t)b * p.in_h * p.in_w * C8 + c8;
+    uint4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C8 + c8;
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
+    auto load_row = [&](int iy, uint4 (&dst)[4]) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const uint4* xr = xb + (int64_t)(rowok ? iy : 0) * p.in_w * C8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = rowok && ((colmask >> t) & 1u);
+            const uint4 v = xr[(int64_t)(ok ? ix0 + t : 0) * C8];
+            const unsigned m = ok ? 0xffffffffu : 0u;
+            dst[t] = make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+        }
+    };
+    if (!sep) {      // direct 16-tap form: correct for any FIR, not tuned
+#pragma unroll 1
+        for (int oy = oy0; oy < oy1; ++oy) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                uint4 row[4];
+                load_row(2 * oy - p.pad_y0 + j, row);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float f[8];
+                    unpack8(row[t], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(f[e], sk[4 * j + t], acc[e]);
+                }
+            }
+            yb[(int64_t)oy * p.out_w * C8] = pack8(acc);
+        }
+        return;
+    }
+    auto hfilter = [&](const uint4 (&row)[4], F8& h) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h.v[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float f[8];
+            unpack8(row[t], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h.v[e] = fmaf(f[e], kh[t], h.v[e]);
+        }
+    };
+    F8 h0, h1, h2, h3;
+    {
+        uint4 r0[4], r1[4];
+        load_row(2 * oy0 - p.pad_y0 + 0, r0);
+        load_row(2 * oy0 - p.pad_y0 + 1, r1);
+        hfilter(r0, h0); hfilter(r1, h1);
+    }
+#pragma unroll 1
+    for (int oy = oy0; oy < oy1; ++oy) {
+        uint4 ra[4], rb[4];
+        load_row(2 * oy - p.pad_y0 + 2, ra);
+        load_row(2 * oy - p.pad_y0 + 3, rb);
+        hfilter(ra, h2); hfilter(rb, h3);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = h0.v[e] * kv[0] + h1.v[e] * kv[1] + h2.v[e] * kv[2] + h3.v[e] * kv[3];
+        yb[(int64_t)oy * p.out_w * C8] = pack8(o);
+        h0 = h2; h1 = h3;
+    }
+}
+
+__global__ __launch_bounds__(256) void fir4_up2_bf16x8(uint4* __restrict__ y, const uint4* __restrict__ x, const float* __restrict__ fir,
+                                                       FirParams p, const uint4* __restrict__ resid) {
+    __shared__ float sk[16];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    const int C8 = p.C >> 3;
+    const int bh = (p.out_h + 1) >> 1, bw = (p.out_w + 1) >> 1;          // 2 x 2 output blocks
+    const int segs = (bh + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * bw * C8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int64_t r = idx;
+    const int c8 = (int)(r % C8); r /= C8;
+    const int j = (int)(r % bw); r /= bw;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int i0 = seg * p.seg_rows;
+    const int i1 = (i0 + p.seg_rows < bh) ? i0 + p.seg_rows : bh;
+    // per-axis tap / offset tables (a = output parity), as in fir4_up2_nhwc
+    const int ky0[2] = {p.pad_y0 & 1, (p.pad_y0 - 1) & 1}, kx0[2] = {p.pad_x0 & 1, (p.pad_x0 - 1) & 1};
+    const int dy[2] = {(ky0[0] - p.pad_y0) >> 1, (1 + ky0[1] - p.pad_y0) >> 1};
+    const int dx[2] = {(kx0[0] - p.pad_x0) >> 1, (1 + kx0[1] - p.pad_x0) >> 1};
+    const int ey = dy[1] - dy[0], ex = dx[1] - dx[0];
+    float wq[2][2][2][2];                                                  // [a][bb][u][v]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) wq[a][bb][u][v] = sk[(ky0[a] + 2 * u) * 4 + kx0[bb] + 2 * v];
+    const uint4* xb = x + (int64_t)b * p.in_h * p.in_w * C8 + c8;
+    const int cx0 = j + dx[0];
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) colmask |= ((cx0 + t >= 0) && (cx0 + t < p.in_w)) ? (1u << t) : 0u;
+    auto load_row = [&](int iy, F8 (&dst)[3]) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const uint4* xr = xb + (int64_t)(rowok ? iy : 0) * p.in_w * C8;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const bool ok = rowok && ((colmask >> t) & 1u);
+            const uint4 v = xr[(int64_t)(ok ? cx0 + t : 0) * C8];
+            const unsigned m = ok ? 0xffffffffu : 0u;
+            unpack8(make_uint4(v.x & m, v.y & m, v.z & m, v.w & m), dst[t].v);
+        }
+    };
+    F8 R0[3], R1[3], R2[3];
+    load_row(i0 + dy[0] + 0, R0);
+    load_row(i0 + dy[0] + 1, R1);
+    const bool colB = 2 * j + 1 < p.out_w;
+#pragma unroll 1
+    for (int i = i0; i < i1; ++i) {
+        load_row(i + dy[0] + 2, R2);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = 2 * i + a;
+            if (oy >= p.out_h) break;
+            const bool hi = (a == 1) && (ey == 1);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                if (bb == 1 && !colB) break;
+                const bool hx = (bb == 1) && (ex == 1);
+                const float w00 = wq[a][bb][0][0], w01 = wq[a][bb][0][1], w10 = wq[a][bb][1][0], w11 = wq[a][bb][1][1];
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float top0 = hi ? R1[0].v[e] : R0[0].v[e], top1 = hi ? R1[1].v[e] : R0[1].v[e], top2 = hi ? R1[2].v[e] : R0[2].v[e];
+                    const float bot0 = hi ? R2[0].v[e] : R1[0].v[e], bot1 = hi ? R2[1].v[e] : R1[1].v[e], bot2 = hi ? R2[2].v[e] : R1[2].v[e];
+                    const float t0 = hx ? top1 : top0, t1 = hx ? top2 : top1, b0 = hx ? bot1 : bot0, b1 = hx ? bot2 : bot1;
+                    o[e] = t0 * w00 + t1 * w01 + b0 * w10 + b1 * w11;
+                }
+                const int64_t yi = (((int64_t)b * p.out_h + oy) * p.out_w + 2 * j + bb) * C8 + c8;
+                if (resid) {
+                    const uint4 q = pack8(o);          // the two-kernel chain stores the FIR (bf16) first
+                    unpack8(q, o);
+                    float rf[8];
+                    unpack8(resid[yi], rf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += rf[e];
+                }
+                y[yi] = pack8(o);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { R0[t] = R1[t]; R1[t] = R2[t]; }
+    }
+}
+
 // ---------------- NCHW tiled blur, up = down = 1, k <= 4 -------------------------------------------
 #define TNH 16
 #define TNW 64
@@ -649,7 +845,10 @@ static int upfirdn2d_impl(void* y, const void* x, const float* fir, int B, int C
         const int segs = (out_h + p.seg_rows - 1) / p.seg_rows;
         const int64_t grid = ideas_cdiv((int64_t)B * segs * out_w * (C / 4), 256);
         if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
-        if (dtype == IDEAS_BF16)
+        if (dtype == IDEAS_BF16 && C % 8 == 0)
+            hipLaunchKernelGGL(fir4_down2_bf16x8, dim3((unsigned)ideas_cdiv((int64_t)B * segs * out_w * (C / 8), 256)), dim3(256), 0, stream,
+                               (uint4*)y, (const uint4*)x, fir, p);
+        else if (dtype == IDEAS_BF16)
             hipLaunchKernelGGL(fir4_down2_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
                                (const ideas_bf16x4*)x, fir, p);
         else
@@ -663,7 +862,10 @@ static int upfirdn2d_impl(void* y, const void* x, const float* fir, int B, int C
         const int segs = (bh + p.seg_rows - 1) / p.seg_rows;
         const int64_t grid = ideas_cdiv((int64_t)B * segs * bw * (C / 4), 256);
         if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
-        if (dtype == IDEAS_BF16)
+        if (dtype == IDEAS_BF16 && C % 8 == 0)
+            hipLaunchKernelGGL(fir4_up2_bf16x8, dim3((unsigned)ideas_cdiv((int64_t)B * segs * bw * (C / 8), 256)), dim3(256), 0, stream,
+                               (uint4*)y, (const uint4*)x, fir, p, (const uint4*)resid);
+        else if (dtype == IDEAS_BF16)
             hipLaunchKernelGGL(fir4_up2_nhwc<ideas_bf16x4>, dim3((unsigned)grid), dim3(256), 0, stream, (ideas_bf16x4*)y,
                                (const ideas_bf16x4*)x, fir, p, (const ideas_bf16x4*)resid);
         else

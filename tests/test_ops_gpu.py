@@ -128,7 +128,10 @@ def test_upfirdn2d_random_with_double_backward(ops, shape, pad, gain, cl):
 
 @pytest.mark.parametrize("case", [((2, 8, 32, 32), 1, 2, (1, 1)), ((2, 12, 33, 31), 1, 2, (2, 2)), ((1, 64, 64, 64), 1, 2, (1, 1)),
                                   ((2, 8, 16, 16), 2, 1, (2, 1)), ((2, 12, 17, 15), 2, 1, (2, 2)), ((1, 64, 32, 32), 2, 1, (2, 1)),
-                                  ((2, 4, 9, 9), 2, 1, (1, 1)), ((2, 4, 5, 7), 2, 1, (3, 2)), ((2, 4, 10, 6), 1, 2, (0, 3))])
+                                  ((2, 4, 9, 9), 2, 1, (1, 1)), ((2, 4, 5, 7), 2, 1, (3, 2)), ((2, 4, 10, 6), 1, 2, (0, 3)),
+                                  # 8-channel multiples: the bf16 fir4_down2_bf16x8 / fir4_up2_bf16x8 kernels on odd sizes / pads
+                                  ((2, 16, 17, 15), 2, 1, (2, 2)), ((2, 8, 5, 7), 2, 1, (3, 2)), ((2, 8, 10, 6), 1, 2, (0, 3)),
+                                  ((2, 16, 33, 31), 1, 2, (2, 2)), ((1, 8, 9, 9), 2, 1, (1, 1))])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_fir_at_output_resolution_vs_oracle(ops, case, bf16):
     """The decimating (down = 2) and zero-stuffing (up = 2) 4x4 FIR kernels behind the 1x1 stride-2 skip convs (csrc/upfirdn2d.hip
@@ -152,6 +155,18 @@ def test_fir_at_output_resolution_vs_oracle(ops, case, bf16):
     (ggyd,) = torch.autograd.grad(gxd, gyd, dev(ggx.float(), True).to(dt))
     tol = 6e-3 if bf16 else 2e-6          # bf16: one output rounding (2^-9 relative per element)
     assert rel_err(yd, y) < tol and rel_err(gxd, gx) < tol and rel_err(ggyd, ggy) < tol, (rel_err(yd, y), rel_err(gxd, gx), rel_err(ggyd, ggy))
+
+
+@pytest.mark.parametrize("up,down,pad", [(1, 2, (2, 1)), (2, 1, (2, 1))])
+def test_bf16_fir_kernels_take_a_non_separable_fir(ops, up, down, pad):
+    """fir4_down2_bf16x8 uses the outer-product structure of make_kernel's tables; a rank > 1 FIR must take its direct loop (and
+    fir4_up2_bf16x8 never assumes separability): random 4x4 taps against the f64 oracle."""
+    torch.manual_seed(21)
+    k = torch.randn(4, 4)
+    x = torch.randn(2, 16, 14, 10).to(torch.bfloat16)
+    y = O.upfirdn2d(x.double(), k.double(), up=up, down=down, pad=pad)
+    yd = ops.upfirdn2d(dev(x.float(), True).to(torch.bfloat16), dev(k), up=up, down=down, pad=pad)
+    assert rel_err(yd, y) < 6e-3
 
 
 @pytest.mark.parametrize("kind", ["down", "up"])
