@@ -199,8 +199,11 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
     else:
         peak, kern = PEAK_F32_MFMA_TFLOPS, "conv3x3_wino_wgrad_kernel / conv_wgrad_kernel (f32 MFMA)"
     elem = 2 if bf16 else 4
+    traffic = note = None
+    if batch == 32 and (bf16 or (CV.MATH == _lib.F32_B3 and not CV.B3_WINO_WGRAD)):
+        traffic, note = _pmc_traffic("conv_bf16_wgrad_kernel" if bf16 else "conv_b3_wgrad_kernel", "r02_pmc_bf16wg" if bf16 else "r02_pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, split-K in XCD-banded "
+            "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, split-K in XCD-banded "
             "order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
             "algorithmic_bytes_per_launch": 2.0 * batch * 256 * 256 * 128 * elem}
 

@@ -20,8 +20,8 @@ for f in files:
 json.dump({"files": files, "sha": h.hexdigest()[:16]}, open(sys.argv[1], "w"))
 EOF
 }
-run_one() {   # $1 = precision, $2 = tag, $3.. = kernel source files
-  P=$1; T=$2; shift 2
+run_one() {   # $1 = precision, $2 = tag, $3 = weight-gradient kernel source, $4.. = forward kernel source files
+  P=$1; T=$2; WG=$3; shift 3
   timeout 900 python $R/bench.py --precision $P > $OUT/${T}_bench_default.log 2>&1
   tail -1 $OUT/${T}_bench_default.log > $OUT/${T}_bench_default.json
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_roofline -- python $R/bench.py --precision $P --roofline only > $OUT/${T}_roofline.log 2>&1
@@ -33,7 +33,8 @@ run_one() {   # $1 = precision, $2 = tag, $3.. = kernel source files
     timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${T}_pmc_$tag -- python $R/bench.py --precision $P --roofline only --roofline-launches 6 > $OUT/${T}_pmc_$tag.log 2>&1
   done
   sha $OUT/${T}_source.json "$@"
+  sha $OUT/${T}_wgrad_source.json $WG b3.hpp common.hpp
 }
-if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wino.hip b3.hpp common.hpp; fi
-if [ "$WHAT" = "bf16" ] || [ "$WHAT" = "both" ]; then run_one bf16 bf16 conv_bf16.hip common.hpp; fi
+if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wgrad.hip conv_b3_wino.hip b3.hpp common.hpp; fi
+if [ "$WHAT" = "bf16" ] || [ "$WHAT" = "both" ]; then run_one bf16 bf16 conv_bf16.hip conv_bf16.hip common.hpp; fi
 ls $OUT | head -60

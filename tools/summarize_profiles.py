@@ -14,6 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, rnd = sys.argv[1], sys.argv[2]
 KERNEL = {"f32": "conv_b3_wino_kernel", "bf16": "conv_bf16_kernel"}
+WGRAD = {"f32": ("conv_b3_wgrad_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
 NAMES = {"fetch_size": "fetch_size", "write_size": "write_size", "sq_wave_cycles": "sq_wave", "sq_insts_valu": "sq_insts",
          "sq_lds_bank_conflict": "lds_grbm"}
 for tag, kern in KERNEL.items():
@@ -30,12 +31,16 @@ for tag, kern in KERNEL.items():
         if not f:
             continue
         rows = list(csv.DictReader(open(f[0])))
-        keep = [r for r in rows if kern in r["Kernel_Name"]]
-        if keep:
-            with open(pre + "_" + short + ".csv", "w", newline="") as fp:
-                w = csv.DictWriter(fp, fieldnames=list(keep[0].keys()), quoting=csv.QUOTE_ALL)
-                w.writeheader()
-                w.writerows(keep)
+        wk, wtag = WGRAD[tag]
+        for kname, prefix in ((kern, pre), (wk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wtag}"))):
+            keep = [r for r in rows if kname + "<" in r["Kernel_Name"] or kname + "(" in r["Kernel_Name"]]
+            if keep:
+                with open(prefix + "_" + short + ".csv", "w", newline="") as fp:
+                    w = csv.DictWriter(fp, fieldnames=list(keep[0].keys()), quoting=csv.QUOTE_ALL)
+                    w.writeheader()
+                    w.writerows(keep)
     if os.path.exists(os.path.join(src, tag + "_source.json")):
         shutil.copy(os.path.join(src, tag + "_source.json"), pre + "_source.json")
+    if os.path.exists(os.path.join(src, tag + "_wgrad_source.json")):
+        shutil.copy(os.path.join(src, tag + "_wgrad_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{WGRAD[tag][1]}_source.json"))
     print(tag, "->", pre + "_*")
