@@ -530,6 +530,159 @@ __global__ __launch_bounds__(256) void blur4_bf16x8(uint4* __restrict__ y, const
     if (EPI == EPI_ACT_BWD) bgrad_flush(s_bg, ep.bgrad, p.C, active, 8 * c8, bsum, 8);
 }
 
+// ---------------- the same, TWO output columns per thread -----------------------------------------------------------------------
+// blur4_bf16x8 issues four 16-byte loads per 16-byte output; a thread that owns the column pair (2q, 2q+1) needs five per row for
+// two outputs (the windows overlap in three columns), i.e. 2.5 loads per output, and keeps two horizontally filtered values per
+// row.  Only for separable FIRs (every FIR of the path; others stay on the one-column kernel).
+template <int EPI>
+__global__ __launch_bounds__(256) void blur4_bf16x8_c2(uint4* __restrict__ y, const uint4* __restrict__ x,
+                                                       const float* __restrict__ fir, FirParams p, FirEpi ep) {
+    __shared__ float sk[16];
+    extern __shared__ float s_bg[];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    float kh[4], kv[4];
+    float kmax = 0.f, res = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { kh[t] = sk[t]; kv[t] = sk[0] != 0.f ? sk[4 * t] / sk[0] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kmax = fmaxf(kmax, fabsf(sk[4 * j + t])); res = fmaxf(res, fabsf(sk[4 * j + t] - kv[j] * kh[t])); }
+    const bool sep = res <= 1e-6f * kmax;           // block-uniform; a rank > 1 table takes the direct loop below
+    const int C8 = p.C >> 3;
+    const int pw = (p.out_w + 1) >> 1;                       // column pairs
+    const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * pw * C8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < total;
+    if (EPI != EPI_ACT_BWD && !active) return;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t r = active ? i : total - 1;      // (see blur4_nhwc: one path to the barriers of bgrad_flush)
+    const int c8 = (int)(r % C8); r /= C8;
+    const int q = (int)(r % pw); r /= pw;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int ox = 2 * q;
+    const bool colB = ox + 1 < p.out_w;
+    const int oy0 = seg * p.seg_rows;
+    const int oy1 = (oy0 + p.seg_rows < p.out_h) ? oy0 + p.seg_rows : p.out_h;
+    const int ix0 = ox - p.pad_x0;
+    const uint4* xb = x + (int64_t)b * p.in_h * p.in_w * C8 + c8;
+    uint4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C8 + c8;
+    const uint4* rb = reinterpret_cast<const uint4*>(ep.ref) + (((int64_t)b * p.out_h) * p.out_w + ox) * C8 + c8;
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[e] = ep.bias[8 * c8 + e];
+    }
+    auto finish = [&](int oy, int col, float (&o)[8]) {
+        const int64_t off = (int64_t)oy * p.out_w * C8 + (int64_t)col * C8;
+        if (EPI != EPI_NONE) {
+            const uint4 qv = pack8(o);
+            unpack8(qv, o);
+        }
+        if (EPI == EPI_ACT_BWD) {
+            float rf[8];
+            unpack8(rb[off], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = epi_act(o[e], rf[e], ep.alpha, ep.scale); bsum[e] += o[e]; }
+            if (!active) return;
+        }
+        if (EPI == EPI_BIAS_ACT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float v = o[e] + bb[e]; o[e] = epi_act(v, v, ep.alpha, ep.scale); }
+        }
+        yb[off] = pack8(o);
+    };
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
+    if (!sep) {      // direct 16-tap form, one output at a time: correct for any FIR, not tuned
+#pragma unroll 1
+        for (int oy = oy0; oy < oy1; ++oy)
+#pragma unroll 1
+            for (int col = 0; col < (colB ? 2 : 1); ++col) {
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    const int iy = oy - p.pad_y0 + j;
+                    if (iy < 0 || iy >= p.in_h) continue;
+#pragma unroll 1
+                    for (int t = 0; t < 4; ++t) {
+                        const int ix = ix0 + col + t;
+                        if (ix < 0 || ix >= p.in_w) continue;
+                        float f[8];
+                        unpack8(xb[((int64_t)iy * p.in_w + ix) * C8], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(f[e], sk[4 * j + t], acc[e]);
+                    }
+                }
+                finish(oy, col, acc);
+            }
+        if (EPI == EPI_ACT_BWD) bgrad_flush(s_bg, ep.bgrad, p.C, active, 8 * c8, bsum, 8);
+        return;
+    }
+    // one input row -> its two horizontally filtered values (columns ox and ox + 1)
+    auto hrow = [&](int iy, F8& ha, F8& hb) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const uint4* xr = xb + (int64_t)(rowok ? iy : 0) * p.in_w * C8;
+        uint4 v[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const bool ok = rowok && ((colmask >> t) & 1u);
+            const uint4 w = xr[(int64_t)(ok ? ix0 + t : 0) * C8];
+            const unsigned m = ok ? 0xffffffffu : 0u;
+            v[t] = make_uint4(w.x & m, w.y & m, w.z & m, w.w & m);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ha.v[e] = 0.f; hb.v[e] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            float f[8];
+            unpack8(v[t], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (t < 4) ha.v[e] = fmaf(f[e], kh[t], ha.v[e]);
+                if (t > 0) hb.v[e] = fmaf(f[e], kh[t - 1], hb.v[e]);
+            }
+        }
+    };
+    auto emit = [&](int oy, const F8& a0, const F8& a1, const F8& a2, const F8& a3, const F8& b0, const F8& b1, const F8& b2, const F8& b3) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a0.v[e] * kv[0] + a1.v[e] * kv[1] + a2.v[e] * kv[2] + a3.v[e] * kv[3];
+        finish(oy, 0, o);
+        if (colB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = b0.v[e] * kv[0] + b1.v[e] * kv[1] + b2.v[e] * kv[2] + b3.v[e] * kv[3];
+            finish(oy, 1, o);
+        }
+    };
+    F8 a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    {
+        const int iy0 = oy0 - p.pad_y0;
+        hrow(iy0 + 0, a0, b0); hrow(iy0 + 1, a1, b1); hrow(iy0 + 2, a2, b2);
+    }
+    int oy = oy0;
+#pragma unroll 1
+    for (; oy + 1 < oy1; oy += 2) {      // two output rows per trip: ten 16-byte loads in flight
+        hrow(oy - p.pad_y0 + 3, a3, b3);
+        hrow(oy - p.pad_y0 + 4, a4, b4);
+        emit(oy, a0, a1, a2, a3, b0, b1, b2, b3);
+        emit(oy + 1, a1, a2, a3, a4, b1, b2, b3, b4);
+        a0 = a2; a1 = a3; a2 = a4; b0 = b2; b1 = b3; b2 = b4;
+    }
+    if (oy < oy1) {
+        hrow(oy - p.pad_y0 + 3, a3, b3);
+        emit(oy, a0, a1, a2, a3, b0, b1, b2, b3);
+    }
+    if (EPI == EPI_ACT_BWD) bgrad_flush(s_bg, ep.bgrad, p.C, active, 8 * c8, bsum, 8);
+}
+
 // ---------------- bf16 NHWC decimating / zero-stuffing 4x4 FIRs, 8 channels (16 bytes) per thread ------------------------------
 // Same reason as blur4_bf16x8: with 2-byte elements the 4-channel kernels above move 8 bytes per lane and instruction and are
 // latency-bound (fir4_up2 / fir4_down2 on bf16: ~1.5 TB/s).  down2 keeps a window of four horizontally filtered rows (the FIR is an
@@ -786,6 +939,15 @@ static int launch_blur4(void* y, const void* x, const float* fir, FirParams p, F
     const int64_t grid = ideas_cdiv(total, 256);
     if (grid > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const size_t lds = EPI == EPI_ACT_BWD ? (size_t)p.C * sizeof(float) : 0;
+#ifndef IDEAS_BLUR_C2
+#define IDEAS_BLUR_C2 1
+#endif
+    if (IDEAS_BLUR_C2 && dtype == IDEAS_BF16 && p.C % 8 == 0) {
+        const int64_t total8 = (int64_t)p.B * segs * ((p.out_w + 1) / 2) * (p.C / 8);
+        hipLaunchKernelGGL(blur4_bf16x8_c2<EPI>, dim3((unsigned)ideas_cdiv(total8, 256)), dim3(256), lds, stream, (uint4*)y,
+                           (const uint4*)x, fir, p, ep);
+        return ideas_launch_status();
+    }
     if (dtype == IDEAS_BF16 && p.C % 8 == 0) {
         const int64_t total8 = (int64_t)p.B * segs * p.out_w * (p.C / 8);
         hipLaunchKernelGGL(blur4_bf16x8<EPI>, dim3((unsigned)ideas_cdiv(total8, 256)), dim3(256), lds, stream, (uint4*)y,
