@@ -369,6 +369,152 @@ __global__ __launch_bounds__(256) void fir4_up2_nhwc(V* __restrict__ y, const V*
     }
 }
 
+// ---------------- f32 NHWC 4x4 blur, two output columns per thread (separable FIR) ---------------------------------------------
+// blur4_nhwc issues four 16-byte loads per 16-byte output and is bound by load instructions, not by HBM (4.5-5.0 TB/s against the
+// 5.5-6 of a plain streaming kernel).  A thread that owns the column pair (2q, 2q+1) loads five vectors per row for two outputs and
+// -- every FIR of the path being an outer product kv (x) kh (make_kernel, stylegan2/model.py:22-30) -- keeps two horizontally
+// filtered values per row instead of a 4 x 5 window.  The factorisation is checked on the device; a rank > 1 table takes a direct
+// loop.  (Summation order differs from blur4_nhwc in the last bit; fused and unfused stages share this kernel, so they still agree
+// bitwise with each other.)
+template <int EPI>
+__global__ __launch_bounds__(256) void blur4_f32_c2(float4* __restrict__ y, const float4* __restrict__ x,
+                                                    const float* __restrict__ fir, FirParams p, FirEpi ep) {
+    __shared__ float sk[16];
+    extern __shared__ float s_bg[];
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        sk[t] = fir[p.flip ? 15 - t : t] * p.gain;
+    }
+    __syncthreads();
+    float kh[4], kv[4];
+    float kmax = 0.f, res = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { kh[t] = sk[t]; kv[t] = sk[0] != 0.f ? sk[4 * t] / sk[0] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kmax = fmaxf(kmax, fabsf(sk[4 * j + t])); res = fmaxf(res, fabsf(sk[4 * j + t] - kv[j] * kh[t])); }
+    const bool sep = res <= 1e-6f * kmax;           // block-uniform
+    const int C4 = p.C >> 2;
+    const int pw = (p.out_w + 1) >> 1;
+    const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
+    const int64_t total = (int64_t)p.B * segs * pw * C4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < total;
+    if (EPI != EPI_ACT_BWD && !active) return;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t r = active ? i : total - 1;      // (see blur4_nhwc: one path to the barriers of bgrad_flush)
+    const int c4 = (int)(r % C4); r /= C4;
+    const int q = (int)(r % pw); r /= pw;
+    const int seg = (int)(r % segs);
+    const int b = (int)(r / segs);
+    const int ox = 2 * q;
+    const bool colB = ox + 1 < p.out_w;
+    const int oy0 = seg * p.seg_rows;
+    const int oy1 = (oy0 + p.seg_rows < p.out_h) ? oy0 + p.seg_rows : p.out_h;
+    const int ix0 = ox - p.pad_x0;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xb = x + (int64_t)b * p.in_h * p.in_w * C4 + c4;
+    float4* yb = y + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    const float4* rb = reinterpret_cast<const float4*>(ep.ref) + (((int64_t)b * p.out_h) * p.out_w + ox) * C4 + c4;
+    float4 bb = zero;
+    if (EPI == EPI_BIAS_ACT) bb = *reinterpret_cast<const float4*>(ep.bias + 4 * c4);
+    auto finish = [&](int oy, int col, float4 acc) {
+        const int64_t off = (int64_t)oy * p.out_w * C4 + (int64_t)col * C4;
+        if (EPI == EPI_ACT_BWD) {
+            const float4 rf = rb[off];
+            acc = make_float4(epi_act(acc.x, rf.x, ep.alpha, ep.scale), epi_act(acc.y, rf.y, ep.alpha, ep.scale),
+                              epi_act(acc.z, rf.z, ep.alpha, ep.scale), epi_act(acc.w, rf.w, ep.alpha, ep.scale));
+            bsum.x += acc.x; bsum.y += acc.y; bsum.z += acc.z; bsum.w += acc.w;
+            if (!active) return;
+        }
+        if (EPI == EPI_BIAS_ACT) {
+            const float4 v = make_float4(acc.x + bb.x, acc.y + bb.y, acc.z + bb.z, acc.w + bb.w);
+            acc = make_float4(epi_act(v.x, v.x, ep.alpha, ep.scale), epi_act(v.y, v.y, ep.alpha, ep.scale),
+                              epi_act(v.z, v.z, ep.alpha, ep.scale), epi_act(v.w, v.w, ep.alpha, ep.scale));
+        }
+        yb[off] = acc;
+    };
+    unsigned colmask = 0;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) colmask |= ((ix0 + t >= 0) && (ix0 + t < p.in_w)) ? (1u << t) : 0u;
+    if (!sep) {      // direct 16-tap form, one output at a time: correct for any FIR, not tuned
+#pragma unroll 1
+        for (int oy = oy0; oy < oy1; ++oy)
+#pragma unroll 1
+            for (int col = 0; col < (colB ? 2 : 1); ++col) {
+                float4 acc = zero;
+#pragma unroll 1
+                for (int j = 0; j < 4; ++j) {
+                    const int iy = oy - p.pad_y0 + j;
+                    if (iy < 0 || iy >= p.in_h) continue;
+#pragma unroll 1
+                    for (int t = 0; t < 4; ++t) {
+                        const int ix = ix0 + col + t;
+                        if (ix < 0 || ix >= p.in_w) continue;
+                        const float4 v = xb[((int64_t)iy * p.in_w + ix) * C4];
+                        const float kk = sk[4 * j + t];
+                        acc.x = fmaf(v.x, kk, acc.x); acc.y = fmaf(v.y, kk, acc.y); acc.z = fmaf(v.z, kk, acc.z); acc.w = fmaf(v.w, kk, acc.w);
+                    }
+                }
+                finish(oy, col, acc);
+            }
+        if (EPI == EPI_ACT_BWD) {
+            const float part[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+            bgrad_flush(s_bg, ep.bgrad, p.C, active, 4 * c4, part, 4);
+        }
+        return;
+    }
+    // one input row -> its two horizontally filtered values (columns ox and ox + 1); loads are clamped + masked by value
+    // (component-wise: a ternary on the float4 aggregate becomes a select between ADDRESSES and spills to scratch)
+    auto hrow = [&](int iy, float4& ha, float4& hb) {
+        const bool rowok = (iy >= 0) && (iy < p.in_h);
+        const float4* xr = xb + (int64_t)(rowok ? iy : 0) * p.in_w * C4;
+        float4 v[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const bool ok = rowok && ((colmask >> t) & 1u);
+            const float4 w = xr[(int64_t)(ok ? ix0 + t : 0) * C4];
+            v[t] = make_float4(ok ? w.x : 0.f, ok ? w.y : 0.f, ok ? w.z : 0.f, ok ? w.w : 0.f);
+        }
+        ha = zero; hb = zero;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (t < 4) { ha.x = fmaf(v[t].x, kh[t], ha.x); ha.y = fmaf(v[t].y, kh[t], ha.y); ha.z = fmaf(v[t].z, kh[t], ha.z); ha.w = fmaf(v[t].w, kh[t], ha.w); }
+            if (t > 0) { hb.x = fmaf(v[t].x, kh[t - 1], hb.x); hb.y = fmaf(v[t].y, kh[t - 1], hb.y); hb.z = fmaf(v[t].z, kh[t - 1], hb.z); hb.w = fmaf(v[t].w, kh[t - 1], hb.w); }
+        }
+    };
+    auto vsum = [&](const float4& r0, const float4& r1, const float4& r2, const float4& r3) {
+        return make_float4(r0.x * kv[0] + r1.x * kv[1] + r2.x * kv[2] + r3.x * kv[3], r0.y * kv[0] + r1.y * kv[1] + r2.y * kv[2] + r3.y * kv[3],
+                           r0.z * kv[0] + r1.z * kv[1] + r2.z * kv[2] + r3.z * kv[3], r0.w * kv[0] + r1.w * kv[1] + r2.w * kv[2] + r3.w * kv[3]);
+    };
+    float4 a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    {
+        const int iy0 = oy0 - p.pad_y0;
+        hrow(iy0 + 0, a0, b0); hrow(iy0 + 1, a1, b1); hrow(iy0 + 2, a2, b2);
+    }
+    int oy = oy0;
+#pragma unroll 1
+    for (; oy + 1 < oy1; oy += 2) {      // two output rows per trip: ten 16-byte loads in flight
+        hrow(oy - p.pad_y0 + 3, a3, b3);
+        hrow(oy - p.pad_y0 + 4, a4, b4);
+        finish(oy, 0, vsum(a0, a1, a2, a3));
+        if (colB) finish(oy, 1, vsum(b0, b1, b2, b3));
+        finish(oy + 1, 0, vsum(a1, a2, a3, a4));
+        if (colB) finish(oy + 1, 1, vsum(b1, b2, b3, b4));
+        a0 = a2; a1 = a3; a2 = a4; b0 = b2; b1 = b3; b2 = b4;
+    }
+    if (oy < oy1) {
+        hrow(oy - p.pad_y0 + 3, a3, b3);
+        finish(oy, 0, vsum(a0, a1, a2, a3));
+        if (colB) finish(oy, 1, vsum(b0, b1, b2, b3));
+    }
+    if (EPI == EPI_ACT_BWD) {
+        const float part[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+        bgrad_flush(s_bg, ep.bgrad, p.C, active, 4 * c4, part, 4);
+    }
+}
+
 // ---------------- bf16 NHWC 4x4 blur, 8 channels (16 bytes) per thread -------------------------------------------------
 // With 2-byte elements the 4-channel window kernel above moves half the bytes per instruction and is latency-bound
 // (1.45 TB/s measured).  Here a thread owns 8 channels of one output column.  A 4x4 window of 8-channel inputs would be 128
@@ -955,7 +1101,11 @@ static int launch_blur4(void* y, const void* x, const float* fir, FirParams p, F
     } else if (dtype == IDEAS_BF16)
         hipLaunchKernelGGL((blur4_nhwc<ideas_bf16x4, EPI>), dim3((unsigned)grid), dim3(256), lds, stream, (ideas_bf16x4*)y,
                            (const ideas_bf16x4*)x, fir, p, ep);
-    else
+    else if (IDEAS_BLUR_C2) {
+        const int64_t total2 = (int64_t)p.B * segs * ((p.out_w + 1) / 2) * (p.C / 4);
+        hipLaunchKernelGGL(blur4_f32_c2<EPI>, dim3((unsigned)ideas_cdiv(total2, 256)), dim3(256), lds, stream, (float4*)y,
+                           (const float4*)x, fir, p, ep);
+    } else
         hipLaunchKernelGGL((blur4_nhwc<float4, EPI>), dim3((unsigned)grid), dim3(256), lds, stream, (float4*)y, (const float4*)x, fir,
                            p, ep);
     return ideas_launch_status();
