@@ -138,6 +138,63 @@ __global__ __launch_bounds__(256) void pointwise_smallk_kernel(T* __restrict__ y
     }
 }
 
+// The same with FOUR consecutive output channels per thread (Cout % 4 == 0): one 16-byte (f32) / 8-byte (bf16) store per lane
+// instead of four scalar ones -- the scalar kernel above is bound by store instructions (1.3-1.9 TB/s on from-RGB 3 -> 64 and on
+// to-RGB's input gradient 3 -> 128 at 256x256).  Same per-element operation order.
+template <typename T> struct Vec4Of;
+template <> struct Vec4Of<float> { typedef float4 type; };
+template <> struct Vec4Of<bf16_t> { typedef ideas_bf16x4 type; };
+template <int KMAX, typename T>
+__global__ __launch_bounds__(256) void pointwise_smallk_vec_kernel(T* __restrict__ y, const T* __restrict__ x,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                                   const T* __restrict__ resid, int64_t P, int Cin, int Cout,
+                                                                   float gain, int act, float alpha, float act_gain,
+                                                                   float resid_gain, int accumulate) {
+    typedef typename Vec4Of<T>::type V;
+    const int C4 = Cout >> 2;
+    const int groups = blockDim.x / C4;              // pixel lanes per block
+    const int o4 = threadIdx.x % C4, grp = threadIdx.x / C4;
+    if (grp >= groups) return;
+    float wr[4][KMAX];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) wr[e][k] = k < Cin ? w[(int64_t)(4 * o4 + e) * Cin + k] : 0.f;
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = bias ? bias[4 * o4 + e] : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * groups;
+    V* yv = reinterpret_cast<V*>(y);
+    const V* rv = reinterpret_cast<const V*>(resid);
+    for (int64_t pp = (int64_t)blockIdx.x * groups + grp; pp < P; pp += stride) {
+        const T* xp = x + pp * Cin;
+        float xs[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) xs[k] = k < Cin ? ldv(xp + k) : 0.f;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < Cin) acc = fmaf(xs[k], wr[e][k], acc);
+            float t = mul_then_add(acc, gain, bv[e]);
+            if (act) t = (t > 0.f ? t : t * alpha) * act_gain;
+            v[e] = t;
+        }
+        const int64_t yi = pp * C4 + o4;
+        if (resid) {
+            const float4 r4 = to_f4(rv[yi]);
+            v[0] = (v[0] + r4.x) * resid_gain; v[1] = (v[1] + r4.y) * resid_gain; v[2] = (v[2] + r4.z) * resid_gain; v[3] = (v[3] + r4.w) * resid_gain;
+        }
+        if (accumulate) {
+            const float4 a4 = to_f4(yv[yi]);
+            v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+        }
+        yv[yi] = from_f4<V>(make_float4(v[0], v[1], v[2], v[3]));
+    }
+}
+
 // gw[o][ci] += gain * sum_p gy[p][o] * x[p][ci] with min(Cin, Cout) <= 8.  WIDE_OUT: threads span o (gy coalesced,
 // x broadcast, Cin accumulators); otherwise threads span ci (x coalesced, gy broadcast, Cout accumulators).
 template <int SMALL, bool WIDE_OUT, typename T>
@@ -351,6 +408,18 @@ int conv_direct_impl(void* y, const void* x, const void* wmat, const float* in_s
         if (p->Cout <= 4) { if (IT == 1) ROWDOT(4, 1); else if (IT == 2) ROWDOT(4, 2); else if (IT == 3) ROWDOT(4, 3); else ROWDOT(4, 4); }
         else { if (IT == 1) ROWDOT(8, 1); else if (IT == 2) ROWDOT(8, 2); else if (IT == 3) ROWDOT(8, 3); else ROWDOT(8, 4); }
 #undef ROWDOT
+        return ideas_launch_status();
+    }
+    if (is_pointwise(p) && !in_scale && !out_scale && p->Cin <= 4 && p->Cout % 4 == 0 && p->Cout >= 16 && p->Cout <= 1024 &&
+        ideas_aligned16(y) && (!resid || ideas_aligned16(resid))) {
+        const int64_t P = (int64_t)p->B * p->OH * p->OW;
+        const int groups = 256 / (p->Cout / 4);
+        int64_t grid = ideas_cdiv(P, (int64_t)groups * 8);
+        if (grid > 8192) grid = 8192;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL((pointwise_smallk_vec_kernel<4, T>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (T*)y,
+                           (const T*)x, (const float*)wmat, bias, (const T*)resid, P, p->Cin, p->Cout, p->gain, p->act, p->alpha,
+                           p->act_gain, p->resid_gain, p->accumulate);
         return ideas_launch_status();
     }
     if (is_pointwise(p) && !in_scale && !out_scale && p->Cin <= 8 && p->Cout <= 256) {
