@@ -93,9 +93,27 @@ def cache_begin() -> None:
     _CACHE = {}
 
 
-def cache_clear() -> None:
-    if _CACHE is not None:
+def cache_clear(params=None) -> None:
+    """Drop the derived weights -- all of them, or (``params``: the tensors an optimiser just stepped) only those derived from these
+    parameters: the D step leaves E's / G's packs alone, which the G phase of the same iteration then reuses."""
+    if _CACHE is None:
+        return
+    if params is None:
         _CACHE.clear()
+        return
+    spans = sorted((p.data_ptr(), p.data_ptr() + p.numel() * p.element_size()) for p in params)
+    merged = []
+    for a, b in spans:                       # fused optimisers: the parameters are views of one flat buffer -> a few long spans
+        if merged and a <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], b)
+        else:
+            merged.append([a, b])
+    import bisect
+    starts = [m[0] for m in merged]
+    for k in [k for k in _CACHE]:
+        i = bisect.bisect_right(starts, k[0]) - 1
+        if i >= 0 and k[0] < merged[i][1]:
+            del _CACHE[k]
 
 
 def cache_end() -> None:

@@ -132,7 +132,7 @@ def _step(opt, ema: bool = True) -> None:
     finally:
         if not ema and decay is not None:
             opt.ema_decay = decay
-    conv_plan.cache_clear()
+    conv_plan.cache_clear([p for grp in opt.param_groups for p in grp["params"]])
 
 
 def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optional[StepDraws] = None,

@@ -193,7 +193,8 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
 
 def test_derived_weight_cache_scope():
     """op/conv_plan.py cache: off by default (plain op calls never see stale derived weights), memoises only (views of)
-    Parameters while on, and is emptied by cache_clear() -- which train_step._step calls after every optimiser step."""
+    Parameters while on, and is emptied by cache_clear() -- which train_step._step calls after every optimiser step with that
+    optimiser's parameters, so the other networks' derived weights survive."""
     import torch
     from ideas_amd.op import conv_plan as P
     w = torch.nn.Parameter(torch.randn(4, 3, 3, 3))
@@ -213,8 +214,17 @@ def test_derived_weight_cache_scope():
         t = torch.randn(4, 3, 3, 3)                          # not a Parameter: never cached
         P.cached(t, ("k",), make); P.cached(t, ("k",), make)
         n = len(calls)
-        P.cache_clear()                                      # what an optimiser step triggers
+        P.cache_clear()                                      # a full clear
         assert P.cached(w, ("k",), make) is not a and len(calls) == n + 1
+        # what an optimiser step triggers: only what derives from the parameters it stepped (views of a flat buffer included)
+        flat = torch.nn.Parameter(torch.randn(100))
+        other = torch.nn.Parameter(torch.randn(2, 3, 3, 3))
+        va, vb = flat[:54].view(2, 3, 3, 3), flat[54:]
+        ea, eb, eo, ew = (P.cached(va, ("k",), make), P.cached(vb, ("k",), make), P.cached(other, ("k",), make),
+                          P.cached(w, ("k",), make))
+        P.cache_clear([flat])
+        assert P.cached(other, ("k",), make) is eo and P.cached(w, ("k",), make) is ew       # untouched parameters keep their entries
+        assert P.cached(va, ("k",), make) is not ea and P.cached(vb, ("k",), make) is not eb
     finally:
         P.cache_end()
     assert P._CACHE is None
