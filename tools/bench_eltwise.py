@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ideas_amd.op.fused_act import bias_act_raw  # noqa: E402
-from ideas_amd.op.upfirdn2d import upfirdn2d_raw  # noqa: E402
+from ideas_amd.op.upfirdn2d import fir_up2_add_raw, upfirdn2d_raw  # noqa: E402
 from ideas_amd.op.modulated_conv import act_bwd_dot, pixel_dot  # noqa: E402
 from ideas_amd.model import make_kernel  # noqa: E402
 
@@ -43,12 +43,18 @@ def main():
         ms4 = timeit(lambda: upfirdn2d_raw(x, fir, (1, 1), (1, 1), (1, 1, 1, 1), (H - 1, H - 1), True))
         ms5 = timeit(lambda: pixel_dot(x, y))
         ms6 = timeit(lambda: act_bwd_dot(x, y, b, 0.2, 1.4))
+        fir4 = fir * 4
+        xh = x[:, :, ::2, ::2].contiguous(memory_format=CL)
+        ms9 = timeit(lambda: upfirdn2d_raw(x, fir, (1, 1), (2, 2), (1, 1, 1, 1), (H // 2, H // 2), True))            # decimating FIR
+        ms10 = timeit(lambda: upfirdn2d_raw(xh, fir4, (2, 2), (1, 1), (2, 1, 2, 1), (H, H), True))                  # zero-stuffing FIR
+        ms11 = timeit(lambda: fir_up2_add_raw(xh, fir4, (2, 1, 2, 1), (H, H), True, y))                             # ... + resid
         ms7 = timeit(lambda: torch.add(x, y))
         ms8 = timeit(lambda: x * 0.7)
         gb = n * es / 1e9
         print(f"[{B},{C},{H},{H}] {gb:6.2f} GB | act fwd {2 * gb / ms * 1e3:6.0f} GB/s | act bwd+bias {3 * gb / ms2 * 1e3:6.0f} | "
               f"blur(2,2) {2 * gb / ms3 * 1e3:6.0f} | blur(1,1) {2 * gb / ms4 * 1e3:6.0f} | pixel_dot {2 * gb / ms5 * 1e3:6.0f} | "
-              f"act_bwd_dot {3 * gb / ms6 * 1e3:6.0f} | torch add {3 * gb / ms7 * 1e3:6.0f} | torch mul {2 * gb / ms8 * 1e3:6.0f}", flush=True)
+              f"act_bwd_dot {3 * gb / ms6 * 1e3:6.0f} | torch add {3 * gb / ms7 * 1e3:6.0f} | torch mul {2 * gb / ms8 * 1e3:6.0f} | "
+              f"fir down2 {1.25 * gb / ms9 * 1e3:6.0f} | fir up2 {1.25 * gb / ms10 * 1e3:6.0f} | fir up2+resid {2.25 * gb / ms11 * 1e3:6.0f}", flush=True)
         del x, y
         torch.cuda.empty_cache()
 
