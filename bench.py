@@ -208,6 +208,36 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
             "algorithmic_bytes_per_launch": 2.0 * batch * 256 * 256 * 128 * elem}
 
 
+def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
+    """Third entry: the largest HBM-bound kernel of the step, the 4x4 blur (blur4_f32_c2 / blur4_bf16x8_c2, upfirdn2d.hip), on the
+    activation it is most expensive on (Dreal.1 / G.7: 128 channels at 256x256).  `achieved` = ALGORITHMIC bytes (read the
+    input once, write the output once) / time, against the 8 TB/s HBM3E peak."""
+    from ideas_amd.model import make_kernel
+    from ideas_amd.op.upfirdn2d import upfirdn2d_raw
+    g = torch.Generator(device="cpu").manual_seed(9)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    x = torch.randn(batch, 128, 256, 256, generator=g).to(device).to(adt).contiguous(memory_format=torch.channels_last)
+    fir = make_kernel((1, 3, 3, 1)).to(device)
+    run = lambda: upfirdn2d_raw(x, fir, (1, 1), (1, 1), (2, 2, 2, 2), (257, 257), True)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    nbytes = (batch * 128 * 256 * 256 + batch * 128 * 257 * 257) * (2 if bf16 else 4)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r02_pmc_blurbf16" if bf16 else "r02_pmc_blurf32") if batch == 32 else (None, None)
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+            "traffic_source": note,
+            "kernel": ("blur4_bf16x8_c2<0>" if bf16 else "blur4_f32_c2<0>") + " (4x4 FIR of a downsampling ConvLayer, two output columns per thread) on "
+            "[%d,128,256,256] -> 257x257, pad (2,2)" % batch, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4)}
+
+
 def _src_sha(files):
     import hashlib
     h = hashlib.sha256()
@@ -393,7 +423,8 @@ def main():
     probe = roofline_probe_bf16 if bf16 else roofline_probe
     if a.roofline == "only":
         print(json.dumps({"roofline": probe(device, a.batch, a.roofline_launches),
-                          "roofline_wgrad": roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16)}))
+                          "roofline_wgrad": roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16),
+                          "roofline_hbm": roofline_probe_hbm(device, a.batch, a.roofline_launches, bf16)}))
         return
     from ideas_amd import precision
     precision.set_activation_dtype(a.precision)
@@ -481,6 +512,7 @@ def main():
         torch.cuda.empty_cache()
         out["roofline"] = probe(device, a.batch, a.roofline_launches)
         out["roofline_wgrad"] = roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16)
+        out["roofline_hbm"] = roofline_probe_hbm(device, a.batch, a.roofline_launches, bf16)
     if a.cpu_baseline == "auto" and world == 1:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_config1"] = cpu_baseline_config1()

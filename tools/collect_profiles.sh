@@ -34,6 +34,7 @@ run_one() {   # $1 = precision, $2 = tag, $3 = weight-gradient kernel source, $4
   done
   sha $OUT/${T}_source.json "$@"
   sha $OUT/${T}_wgrad_source.json $WG b3.hpp common.hpp
+  sha $OUT/${T}_blur_source.json upfirdn2d.hip common.hpp
 }
 if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wgrad.hip conv_b3_wino.hip b3.hpp common.hpp; fi
 if [ "$WHAT" = "bf16" ] || [ "$WHAT" = "both" ]; then run_one bf16 bf16 conv_bf16.hip conv_bf16.hip common.hpp; fi

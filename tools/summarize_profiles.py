@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, rnd = sys.argv[1], sys.argv[2]
 KERNEL = {"f32": "conv_b3_wino_kernel", "bf16": "conv_bf16_kernel"}
 WGRAD = {"f32": ("conv_b3_wgrad_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
+BLUR = {"f32": ("blur4_f32_c2", "blurf32"), "bf16": ("blur4_bf16x8_c2", "blurbf16")}                 # bench.py's roofline_hbm entry
 NAMES = {"fetch_size": "fetch_size", "write_size": "write_size", "sq_wave_cycles": "sq_wave", "sq_insts_valu": "sq_insts",
          "sq_lds_bank_conflict": "lds_grbm"}
 for tag, kern in KERNEL.items():
@@ -32,7 +33,9 @@ for tag, kern in KERNEL.items():
             continue
         rows = list(csv.DictReader(open(f[0])))
         wk, wtag = WGRAD[tag]
-        for kname, prefix in ((kern, pre), (wk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wtag}"))):
+        bk, btag = BLUR[tag]
+        for kname, prefix in ((kern, pre), (wk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wtag}")),
+                              (bk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{btag}"))):
             keep = [r for r in rows if kname + "<" in r["Kernel_Name"] or kname + "(" in r["Kernel_Name"]]
             if keep:
                 with open(prefix + "_" + short + ".csv", "w", newline="") as fp:
@@ -41,6 +44,8 @@ for tag, kern in KERNEL.items():
                     w.writerows(keep)
     if os.path.exists(os.path.join(src, tag + "_source.json")):
         shutil.copy(os.path.join(src, tag + "_source.json"), pre + "_source.json")
+    if os.path.exists(os.path.join(src, tag + "_blur_source.json")):
+        shutil.copy(os.path.join(src, tag + "_blur_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{BLUR[tag][1]}_source.json"))
     if os.path.exists(os.path.join(src, tag + "_wgrad_source.json")):
         shutil.copy(os.path.join(src, tag + "_wgrad_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{WGRAD[tag][1]}_source.json"))
     print(tag, "->", pre + "_*")
