@@ -80,11 +80,7 @@ def blur_fused_raw(x: torch.Tensor, fir: torch.Tensor, pad: Tuple[int, int, int,
 
 def blur_geometry(in_hw: Tuple[int, int], fir: torch.Tensor, pad2: Tuple[int, int]):
     """(pad4, out_hw, g_pad4) of the unit-stride blur ``upfirdn2d(x, fir, pad=pad2)`` (upfirdn2d.py:95-114)."""
-    kh, kw = fir.shape
-    p0, p1 = pad2
-    oh, ow = in_hw[0] + p0 + p1 - kh + 1, in_hw[1] + p0 + p1 - kw + 1
-    g_pad = (kw - p0 - 1, in_hw[1] - ow + p0, kh - p0 - 1, in_hw[0] - oh + p0)
-    return (p0, p1, p0, p1), (oh, ow), g_pad
+    return _geometry(in_hw, fir, 1, 1, pad2)
 
 
 class _BlurBiasAct(Function):
