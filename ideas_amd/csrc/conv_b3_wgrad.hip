@@ -227,7 +227,11 @@ int launch_b3_wgrad_cfg(float* gw, const void* gy, const void* x, const float* i
     // split-K sizing as in conv_igemm.hip: whole waves of resident blocks, >= 16 steps per block
     const int64_t slots = (int64_t)occ * n_cu;
     const int64_t max_splits = ideas_cdiv(P, 16 * 16);
-    int64_t splits = (2 * slots) / tiles;
+    // two waves of resident blocks -- four where every block still reduces >= 4096 pixels: the long reductions of the 128-512
+    // channel layers at >= 64x64 gain 4-6 % from the finer interleaving (164 -> 170, 169 -> 179 TFLOP/s), short ones lose to the
+    // extra atomics (E.2.conv1: 152 -> 123), profiles/r02_wgrad_ab.txt
+    int64_t splits = (4 * slots) / tiles;
+    if (splits < 1 || P / splits < 4096) splits = (2 * slots) / tiles;
     if (splits < 1) splits = 1;
     if (splits > max_splits) splits = max_splits;
     if (splits > 65535) splits = 65535;

@@ -627,7 +627,10 @@ int launch_bf16_wgrad_cfg(float* gw, const void* gy, const void* x, const float*
     const int64_t img = (int64_t)p->OH * p->OW;
     // split-K: about two waves of resident blocks (2 per CU), >= 8 steps each; modulated convs: whole splits inside one image
     const int64_t slots = (WM * WN == 8 ? 1 : 2) * 256;
-    int64_t splits = (2 * slots) / tiles;
+    // (four waves of blocks where every block still reduces >= 4096 pixels, two otherwise: conv_b3_wgrad.hip; bf16: 572 -> 645
+    //  TFLOP/s on 128->128 @256x256, 730 -> 789 on 256->512 @64x64)
+    int64_t splits = (4 * slots) / tiles;
+    if (splits < 1 || P / splits < 4096) splits = (2 * slots) / tiles;
     if (splits < 1) splits = 1;
     int64_t per, spi = 1;
     if (sc) {
