@@ -1077,9 +1077,9 @@ __global__ __launch_bounds__(256) void blur_nchw_tile(float* __restrict__ y, con
 // the unit-stride 4x4 NHWC blur (+ fused stage): shared by ideas_upfirdn2d (EPI_NONE) and ideas_blur_fused
 template <int EPI>
 static int launch_blur4(void* y, const void* x, const float* fir, FirParams p, FirEpi ep, int dtype, hipStream_t stream) {
-    // rows marched per thread: each segment re-reads 3 halo rows (19/16 vs 35/32 of the input); short images keep 16 so
-    // that enough threads exist (measured: 32 is +5 % at 256x256, -5 % at 64x64)
-    p.seg_rows = p.out_h >= 128 ? 32 : 16;
+    // rows marched per thread: each segment re-reads 3 halo rows (19/16 of the input).  With the two-column kernels (half the
+    // threads per row) 16 beats 8 / 24 / 32 / 64 at every size: 5.3-5.5 TB/s against 4.9-5.0 (32) in f32 at 256x256
+    p.seg_rows = 16;
     const int segs = (p.out_h + p.seg_rows - 1) / p.seg_rows;
     const int64_t total = (int64_t)p.B * segs * p.out_w * (p.C / 4);
     const int64_t grid = ideas_cdiv(total, 256);
