@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """IDEAS headline benchmark: train images/sec of the full G+D+Ex iteration at 256x256 (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 and no WORLD_SIZE in the environment: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -54,6 +54,8 @@ def parse():
     p.add_argument("--batch", type=int, default=32, help="images per GPU")
     p.add_argument("--image-size", type=int, default=256)
     p.add_argument("--N", type=int, default=1)
+    p.add_argument("--channel", type=int, default=32, help="base width (train.py:355); anything but 32 is a test configuration, named in the line")
+    p.add_argument("--texture-channel", type=int, default=2048, help="texture code width (train.py:358)")
     p.add_argument("--literal-second-backward", action="store_true",
                    help="re-traverse Ex->E->G->Gstru for the Ex gradient exactly like train.py:214-215")
     p.add_argument("--no-share-forward", action="store_true",
@@ -62,6 +64,10 @@ def parse():
     p.add_argument("--cpu-baseline", choices=["auto", "skip"], default="auto")
     p.add_argument("--roofline", choices=["on", "off", "only"], default="on")
     p.add_argument("--roofline-launches", type=int, default=20)
+    p.add_argument("--also-bf16", choices=["on", "off"], default="on",
+                   help="after the f32 window, time a short bf16 window in the same process and report it under \"bf16\"")
+    p.add_argument("--bf16-steps", type=int, default=16)
+    p.add_argument("--bf16-warmup", type=int, default=4)
     return p.parse_args()
 
 
@@ -238,6 +244,74 @@ def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
             "[%d,128,256,256] -> 257x257, pad (2,2)" % batch, "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4)}
 
 
+def _time_launches(run, launches):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / launches
+
+
+def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
+    """Fourth entry: the DIRECT forward-family kernel (the stride-2 / transposed layers the Winograd kernel does
+    not take; a quarter of the f32 step's kernel time) on its heaviest instance, G.layers.7.conv1: the stride-2 transposed 3x3
+    modconv 256 -> 128 from 128x128 to 257x257 (9.66 GFLOP per sample; the four output-parity phases with
+    4/2/2/1 taps, so no product is spent on stuffed zeros).  One call = everything conv_dgrad_raw launches for it."""
+    from ideas_amd import _lib
+    from ideas_amd.op import conv as CV, conv_plan
+    from ideas_amd.op.conv_plan import ConvGeom, convT_out_size
+    g = torch.Generator(device="cpu").manual_seed(10)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    x = torch.randn(batch, 256, 128, 128, generator=g).to(device).to(adt).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(128, 256, 3, 3, generator=g).to(device).contiguous(memory_format=torch.channels_last))
+    s = (torch.randn(batch, 256, generator=g) * 0.5 + 1).to(device)
+    d = (torch.rand(batch, 128, generator=g) + 0.5).to(device)
+    geom = ConvGeom(3, 3, 2, 0, False)
+    out_hw = convT_out_size(128, 128, geom)
+    wt = w.transpose(0, 1)
+    conv_plan.cache_begin()
+    try:
+        ms = _time_launches(lambda: CV.conv_dgrad_raw(x, wt, geom, out_hw, 0.02, lin=s, lout=d), launches)
+    finally:
+        conv_plan.cache_end()
+    flops = 2.0 * batch * 128 * 128 * 256 * 128 * 9
+    achieved = flops / (ms * 1e-3) / 1e12
+    if bf16:
+        peak, kern = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_kernel (LDS-DMA implicit GEMM)"
+    elif CV.MATH == _lib.F32_B3:
+        peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_b3_kernel (exact 3-way bf16 split, 6 bf16 MFMA products per f32 product)"
+    else:
+        peak, kern = PEAK_F32_MFMA_TFLOPS, "conv_igemm_kernel (f32 MFMA)"
+    elem = 2 if bf16 else 4
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": None, "kernel": kern + " on G.layers.7.conv1: stride-2 transposed 3x3 modconv 256->128, 128x128 -> 257x257, B=%d "
+            "(all output-parity phases of the layer)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "algorithmic_bytes_per_launch": float(batch * (128 * 128 * 256 + 257 * 257 * 128) * elem)}
+
+
+def roofline_probe_bias_act_bwd(device, batch: int, launches: int, bf16: bool):
+    """Second HBM entry: the backward of fused_leaky_relu (bias_act_nhwc_v4, grad = 1: gradient in, saved activation in, gradient out,
+    the bias gradient reduced in the same pass -- fused_act.py:20-49 + the separate .sum of :38) on [B,128,256,256].
+    Algorithmic bytes: 3 tensors (12 B/elem in f32)."""
+    from ideas_amd.op.fused_act import bias_act_raw
+    g = torch.Generator(device="cpu").manual_seed(11)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    gy = torch.randn(batch, 128, 256, 256, generator=g).to(device).to(adt).contiguous(memory_format=torch.channels_last)
+    out = torch.randn(batch, 128, 256, 256, generator=g).to(device).to(adt).contiguous(memory_format=torch.channels_last)
+    acc = torch.zeros(128, device=device)
+    ms = _time_launches(lambda: bias_act_raw(gy, None, out, 1, 0.2, 2 ** 0.5, bias_grad_into=acc), launches)
+    nbytes = 3.0 * gy.numel() * (2 if bf16 else 4)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "kernel": "bias_act_nhwc_v4 (grad=1: leaky-ReLU backward + bias-gradient reduction in one pass) on [%d,128,256,256] %s"
+                      % (batch, "bf16" if bf16 else "f32"), "algorithmic_bytes_per_launch": nbytes, "ms_per_launch": round(ms, 4)}
+
+
 def _src_sha(files):
     import hashlib
     h = hashlib.sha256()
@@ -285,8 +359,9 @@ def vs_rocm_eager(ips: float, a, world: int):
         d = json.load(open(os.path.join(ROOT, "profiles", "r02_eager_comparator.json")))
     except Exception:
         return None
-    if world != 1 or a.batch != d["batch"] or a.image_size != 256 or a.N != 1:
-        return None
+    if world != 1 or a.batch != d["batch"] or a.image_size != 256 or a.N != 1 or a.precision != "f32" \
+            or (a.channel, a.texture_channel) != (32, 2048):
+        return None          # the comparator was measured for the f32 headline configuration only (cudnn.benchmark f32 NCHW)
     nonconv = d.get("nonconv_ms_per_iteration", 0.0)
     lb_ms = d["measured_conv_ms_per_iteration"] + nonconv
     ub = d["batch"] / (lb_ms * 1e-3)
@@ -299,8 +374,9 @@ def vs_rocm_eager(ips: float, a, world: int):
             "source": "profiles/r02_eager_comparator.json (tools/eager_partial.py, tests/eager_baseline.py --stub-convs)"}
 
 
-def _cpu_baseline_worker(R: int, threads: int, B: int = 1):
-    """Runs in a child process: one oracle iteration (D phase + G/Ex phase with backward) at batch B."""
+def _cpu_baseline_worker(R: int, threads: int, B: int = 1, warm: int = 0, iters: int = 1):
+    """Runs in a child process: `warm` untimed + `iters` timed oracle iterations (D phase with backward and Adam step, G/Ex phase
+    with both backwards and Adam steps) at batch B; prints the per-iteration seconds."""
     import oracle.torch_ref as O
     from ideas_amd.models import init_model
     from ideas_amd import train_step as TS
@@ -320,73 +396,113 @@ def _cpu_baseline_worker(R: int, threads: int, B: int = 1):
     X = torch.rand(B, 3, R, R) * 2 - 1
     random.seed(0)
     s = R // 16
-    dr = O.StepDraws(Z_d=torch.rand(B, 1, s, s) * 2 - 1, T2_d=torch.rand(B, 2048) * 2 - 1,
-                     Z_g=torch.rand(B, 1, s, s) * 2 - 1, T2_g=torch.rand(B, 2048) * 2 - 1)
-    if big:
-        dr.boxes_d_fake, dr.boxes_d_real = O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 8)
-        dr.boxes_d_ref, dr.boxes_g_fake, dr.boxes_g_ref = O.draw_boxes(R, R, 32), O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 32)
-    t0 = time.perf_counter()
     d_params = [p for n in ("Dreal", "Dco", "Ddist") if n in nets for p in nets[n].values() if p.requires_grad]
-    total, _, _ = O.d_phase(nets, cfg, sargs, X, dr)
-    torch.autograd.grad(total, d_params, allow_unused=True)
     g_params = [p for n in ("E", "G", "Gstru") for p in nets[n].values() if p.requires_grad]
     ex_params = [p for p in nets["Ex"].values() if p.requires_grad]
-    total, ex_loss, _, _ = O.g_phase(nets, cfg, sargs, X, dr, 1)
-    torch.autograd.grad(ex_loss, ex_params, retain_graph=True)
-    torch.autograd.grad(total, g_params, allow_unused=True)
-    print(json.dumps({"seconds": time.perf_counter() - t0, "threads": torch.get_num_threads()}))
+    r = 16 / 17
+    opts = (torch.optim.Adam(d_params, lr=0.002 * r, betas=(0.0, 0.99 ** r)), torch.optim.Adam(g_params, lr=0.002, betas=(0.0, 0.99)),
+            torch.optim.Adam(ex_params, lr=0.002, betas=(0.0, 0.99)))
+
+    def one():
+        dr = O.StepDraws(Z_d=torch.rand(B, 1, s, s) * 2 - 1, T2_d=torch.rand(B, 2048) * 2 - 1,
+                         Z_g=torch.rand(B, 1, s, s) * 2 - 1, T2_g=torch.rand(B, 2048) * 2 - 1)
+        if big:
+            dr.boxes_d_fake, dr.boxes_d_real = O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 8)
+            dr.boxes_d_ref, dr.boxes_g_fake, dr.boxes_g_ref = O.draw_boxes(R, R, 32), O.draw_boxes(R, R, 8), O.draw_boxes(R, R, 32)
+        total, _, _ = O.d_phase(nets, cfg, sargs, X, dr)
+        for p, g in zip(d_params, torch.autograd.grad(total, d_params, allow_unused=True)):
+            p.grad = g
+        opts[0].step()
+        total, ex_loss, _, _ = O.g_phase(nets, cfg, sargs, X, dr, 1)
+        gex = torch.autograd.grad(ex_loss, ex_params, retain_graph=True)
+        for p, g in zip(g_params, torch.autograd.grad(total, g_params, allow_unused=True)):
+            p.grad = g
+        opts[1].step()
+        for p, g in zip(ex_params, gex):
+            p.grad = g
+        opts[2].step()
+
+    for _ in range(warm):
+        one()
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    print(json.dumps({"seconds": sum(times) / len(times), "each": [round(t, 2) for t in times], "threads": torch.get_num_threads()}))
+
+
+def _cpu_run(R, B, warm, iters, limit):
+    import subprocess
+    threads = min(os.cpu_count() or 1, 64)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(R), str(threads), str(B), str(warm), str(iters)],
+                           capture_output=True, text=True, timeout=limit, cwd=ROOT)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1]), threads
+    except subprocess.TimeoutExpired:
+        pass
+    return None, threads
 
 
 def cpu_baseline():
-    """The oracle's step (oracle/torch_ref.py, the CPU restatement pinned to the reference) on the host cores.
-    Bounded sample: ONE full-width iteration (D phase + G/Ex phase, forward and backward, no R1, no optimiser) at
-    batch 1 — 256x256 with Dco; if that does not finish in 150 s, the 64x64 Dco-less sub-step (BASELINE.json
-    configs[0]).  Runs in a child process (thread count = min(host threads, 64)) so a slow host cannot hang the bench."""
-    import subprocess
-    threads = min(os.cpu_count() or 1, 64)
+    """The oracle's step (oracle/torch_ref.py, the CPU restatement pinned to the reference) on the host cores, at the workload of
+    the headline: 256x256 with Dco, full width.  Bounded sample: ONE iteration (D phase + G/Ex phase, forward, backward and the
+    three Adam steps; no lazy-R1 pass) at batch 1, cold -- a batch-32 iteration would take minutes.  Child process (thread count =
+    min(host threads, 64)) so a slow host cannot hang the bench; falls back to the 64x64 sub-step if it does not finish."""
     for R, limit in ((256, 150), (64, 120)):
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(R), str(threads)],
-                               capture_output=True, text=True, timeout=limit, cwd=ROOT)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode == 0 and line:
-                d = json.loads(line[-1])
-                return {"value": round(1.0 / d["seconds"], 5), "unit": "images/sec", "cores": d["threads"], "kind": "port",
-                        "sample": "1 iteration (D phase + G/Ex phase fwd+bwd, no R1, no optimiser), batch 1, %dx%d, full "
-                                  "width, %s; %.1f s" % (R, R, "with Dco" if R >= 256 else "Dco-less sub-step", d["seconds"])}
-        except subprocess.TimeoutExpired:
-            continue
+        d, threads = _cpu_run(R, 1, 0, 1, limit)
+        if d is not None:
+            return {"value": round(1.0 / d["seconds"], 5), "unit": "images/sec", "cores": d["threads"], "kind": "port",
+                    "sample": "1 cold iteration (D phase + G/Ex phase fwd+bwd + Adam steps, no R1), batch 1, %dx%d, full "
+                              "width, %s; %.1f s" % (R, R, "with Dco" if R >= 256 else "Dco-less sub-step", d["seconds"])}
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "timed out"}
 
 
 def cpu_baseline_config1():
     """BASELINE.json configs[0] beside it: 64x64, batch 4, the Dco-less sub-step (the reference's Dco cannot run below 256x256,
-    models.py:400), one iteration forward + backward on the host cores."""
-    import subprocess
-    threads = min(os.cpu_count() or 1, 64)
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "64", str(threads), "4"],
-                           capture_output=True, text=True, timeout=150, cwd=ROOT)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode == 0 and line:
-            d = json.loads(line[-1])
-            return {"value": round(4.0 / d["seconds"], 4), "unit": "images/sec", "cores": d["threads"], "kind": "port",
-                    "sample": "1 iteration (D phase + G/Ex phase fwd+bwd, Dco-less sub-step, no R1, no optimiser), batch 4, 64x64, "
-                              "full width; %.1f s" % d["seconds"]}
-    except subprocess.TimeoutExpired:
-        pass
+    models.py:400): 1 warm-up + 3 timed iterations on the host cores."""
+    d, threads = _cpu_run(64, 4, 1, 3, 240)
+    if d is not None:
+        return {"value": round(4.0 / d["seconds"], 4), "unit": "images/sec", "cores": d["threads"], "kind": "port",
+                "sample": "mean of 3 timed iterations after 1 warm-up (D phase + G/Ex phase fwd+bwd + Adam steps, Dco-less sub-step, no "
+                          "R1), batch 4, 64x64, full width; %s s" % d["each"]}
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "timed out"}
+
+
+def _self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here, one process per
+    GPU, exactly as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` does
+    (the shape of stylegan2/train.py:372-373 under torch.distributed.launch).  Rank 0's JSON line is the only stdout line."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus and os.environ.get("IDEAS_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"--gpus {a.gpus} but only {have} GPU(s) are visible (IDEAS_BENCH_SHARE_GPU=1 + IDEAS_DIST_BACKEND=gloo "
+                         "runs several ranks on one device, for tests of the multi-rank path only)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // a.gpus))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
 
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
-        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+        _cpu_baseline_worker(*[int(v) for v in sys.argv[2:7]])
         return
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -414,24 +530,62 @@ def main():
         else:
             dist.init_process_group(backend=backend, init_method="env://")
 
-    from ideas_amd import _lib, train_step as TS
-    from ideas_amd.models import init_model
-    from ideas_amd.ddp import GradReducer
+    from ideas_amd import _lib
     _lib.load()
 
     bf16 = a.precision == "bf16"
-    probe = roofline_probe_bf16 if bf16 else roofline_probe
     if a.roofline == "only":
-        print(json.dumps({"roofline": probe(device, a.batch, a.roofline_launches),
-                          "roofline_wgrad": roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16),
-                          "roofline_hbm": roofline_probe_hbm(device, a.batch, a.roofline_launches, bf16)}))
+        print(json.dumps(rooflines(device, a.batch, a.roofline_launches, bf16)))
         return
-    from ideas_amd import precision
-    precision.set_activation_dtype(a.precision)
 
+    res = run_steps(a, a.precision, a.steps, a.warmup, device, world, rank)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    out = step_line(a, a.precision, res, world)
+    out["vs_rocm_eager"] = vs_rocm_eager(out["value"], a, world)
+    if a.roofline == "on":
+        out.update(rooflines(device, a.batch, a.roofline_launches, bf16))
+    if a.also_bf16 == "on" and not bf16 and world == 1:
+        # BASELINE.json configs[4]'s single-GPU part, timed by the same process right after the f32 window: same step, same
+        # synthetic batch, bf16 activations (ideas_amd/precision.py).  A short window (R1 falls on its last step or not at all is
+        # stated in r1_steps_in_window); the full-length figure is `python bench.py --precision bf16`.
+        r2 = run_steps(a, "bf16", a.bf16_steps, a.bf16_warmup, device, world, rank)
+        l2 = step_line(a, "bf16", r2, world)
+        out["bf16"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "step_tflops", "step_frac_of_ceiling", "losses")}
+        out["bf16"]["r1_steps_in_window"] = l2["config"]["r1_steps_in_window"]
+        out["bf16"]["workload"] = l2["config"]["workload"]
+        if a.roofline == "on":
+            out["bf16"]["roofline"] = roofline_probe_bf16(device, a.batch, a.roofline_launches)
+    if a.cpu_baseline == "auto" and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline_config1"] = cpu_baseline_config1()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rooflines(device, batch, launches, bf16):
+    probe = roofline_probe_bf16 if bf16 else roofline_probe
+    return {"roofline": probe(device, batch, launches),
+            "roofline_wgrad": roofline_probe_wgrad(device, batch, launches, bf16),
+            "roofline_direct": roofline_probe_direct(device, batch, launches, bf16),
+            "roofline_hbm": roofline_probe_hbm(device, batch, launches, bf16),
+            "roofline_hbm_bias_act_bwd": roofline_probe_bias_act_bwd(device, batch, launches, bf16)}
+
+
+def run_steps(a, precision_name, steps, warmup, device, world, rank):
+    """Build the trainer in `precision_name`, run `warmup` untimed and exactly `steps` timed iterations between
+    barrier + synchronize pairs; returns the max-over-ranks wall time and what the line needs.  Frees everything on return."""
+    from ideas_amd import precision, train_step as TS
+    from ideas_amd.models import init_model
+    from ideas_amd.ddp import GradReducer
+    precision.set_activation_dtype(precision_name)
     # below 256x256 the reference's co-occurrence discriminator cannot run (models.py:400; SURVEY.md §8(d) configs 1-2): the
     # step is then the Dco-less sub-step, as in the parity fixtures (tests/golden/step_r128.npz)
     args = TS.default_args(image_size=a.image_size, batch_size=a.batch, N=a.N, use_dco=a.image_size >= 256,
+                           channel=a.channel, texture_channel=a.texture_channel,
                            elide_second_backward=not a.literal_second_backward, num_iters=10 ** 9,
                            share_forward=not a.no_share_forward)
     torch.manual_seed(0)              # identical replicas on every rank (no broadcast needed)
@@ -452,13 +606,13 @@ def main():
     def step(idx):
         return TS.train_iteration(trainer, args, X, idx, reducer=reducer)
 
-    for j in range(a.warmup):
+    for j in range(warmup):
         step(args.d_reg_every * 1000 + j)          # first warm-up iteration exercises the R1 branch
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(1, a.steps + 1):
+    for i in range(1, steps + 1):
         losses = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -468,57 +622,69 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    res = {"dt": dt, "steps": steps, "warmup": warmup,
+           "n_r1": sum(1 for i in range(1, steps + 1) if i % args.d_reg_every == 0),
+           "losses": {k: round(float(v.detach()), 4) for k, v in losses.items() if v.numel() == 1},
+           "bucket_bytes": ({k: 4 * int(trainer[k].flat_g.numel()) for k in ("d_optim", "g_optim", "ex_optim") if hasattr(trainer[k], "flat_g")}
+                            if world > 1 else None)}
+    del trainer, reducer, losses, X
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    precision.set_activation_dtype("f32")
+    return res
 
-    n_r1 = sum(1 for i in range(1, a.steps + 1) if i % args.d_reg_every == 0)
+
+def step_line(a, precision_name, res, world):
     from ideas_amd import _lib
     from ideas_amd.op import conv as _CV
-    conv_math = ("bf16 activations in HBM, bf16 MFMA (one product per MFMA) with f32 accumulation and f32 epilogues; f32 master "
-                 "weights, gradients and optimiser state (ideas_amd/precision.py, csrc/conv_bf16.hip)") if bf16 else \
-                ("f32 tensors; MFMA convs contract an exact 3-way bf16 split of both operands (6 bf16 MFMA products per "
-                 "f32 product, f32 accumulate; f32 error class, tests/test_ops_gpu.py)" if _CV.MATH == _lib.F32_B3
-                 else "f32 MFMA (v_mfma_f32_32x32x2_f32)" + (" + 1-D Winograd F(2,3)" if _CV.WINOGRAD else ""))
-    ips = world * a.batch * a.steps / dt
+    bf16 = precision_name == "bf16"
+    dt, steps = res["dt"], res["steps"]
+    if bf16:
+        conv_math = ("bf16 activations in HBM, bf16 MFMA (one product per MFMA) with f32 accumulation and f32 epilogues; f32 master "
+                     "weights, gradients and optimiser state (ideas_amd/precision.py, csrc/conv_bf16.hip)")
+        ceiling, ceiling_note = PEAK_BF16_MFMA_TFLOPS, "dense bf16 MFMA peak"
+    elif _CV.MATH == _lib.F32_B3:
+        conv_math = ("f32 tensors; MFMA convs contract an exact 3-way bf16 split of both operands (6 bf16 MFMA products per "
+                     "f32 product, f32 accumulate; f32 error class, tests/test_ops_gpu.py)")
+        ceiling, ceiling_note = PEAK_BF16_MFMA_TFLOPS / 6.0, "dense bf16 MFMA peak / 6 plane products per f32 product"
+    else:
+        conv_math = "f32 MFMA (v_mfma_f32_32x32x2_f32)" + (" + 1-D Winograd F(2,3)" if _CV.WINOGRAD else "")
+        ceiling, ceiling_note = PEAK_F32_MFMA_TFLOPS, "f32 MFMA peak"
+    ips = world * a.batch * steps / dt
     gflop_img = flop_per_image(not a.literal_second_backward, shared=not a.no_share_forward)
-    out = {
+    full = a.image_size == 256 and (a.channel, a.texture_channel) == (32, 2048)      # the configuration the FLOP model describes
+    tfl = ips / world * gflop_img / 1e3
+    return {
         "metric": "train images/sec at %dx%d (G+D+Ex step)" % (a.image_size, a.image_size), "value": round(ips, 3), "unit": "images/sec",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+        "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": steps, "warmup": res["warmup"], "ms_per_step": round(dt / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision_name, "data": "synthetic",
         "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
-                               "full-width nets, HIP kernels (BASELINE.json configs[%d]%s)"
+                               "%s nets, HIP kernels (BASELINE.json configs[%d]%s)"
                                % (a.N, a.image_size, a.image_size, a.batch,
+                                  "full-width" if (a.channel, a.texture_channel) == (32, 2048) else
+                                  "NARROW (channel %d, texture %d: a test configuration, not the benchmark)" % (a.channel, a.texture_channel),
                                   1 if a.image_size == 128 else (4 if bf16 else (3 if a.N == 2 else 2)),
                                   "" if a.image_size >= 256 else "; Dco-less sub-step: the reference's Dco cannot run below 256x256"),
-                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": n_r1,
-                   "ranks": world, "allreduce_bytes_per_iteration": (
-                       {k: 4 * int(trainer[k].flat_g.numel()) for k in ("d_optim", "g_optim", "ex_optim") if hasattr(trainer[k], "flat_g")}
-                       if world > 1 else None),
+                   "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": res["n_r1"],
+                   "ranks": (dist.get_world_size() if world > 1 else 1),
+                   "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
+                   "grad_exchange": ("one mean all-reduce per optimiser group on its flat gradient buffer, 1/world folded into the collective; "
+                                     "D group overlapped with the G-phase generator forwards, Ex group with the G-side backward") if world > 1 else None,
+                   "allreduce_bytes_per_iteration": res["bucket_bytes"],
                    "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
                    "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off",
                    "conv_arithmetic": conv_math},
-        # (the FLOP model is the 256x256 one of SURVEY.md §8(d); other sizes report throughput only)
-        "step_gflop_per_image": round(gflop_img, 1) if a.image_size == 256 else None,
-        "step_tflops": round(ips / world * gflop_img / 1e3, 2) if a.image_size == 256 else None,   # algorithmic FLOPs of the step / time, per GPU
-        # ... over the matrix peak of the arithmetic: f32 MFMA (157.3) for the f32 line, dense bf16 MFMA (2500) for the bf16 line
-        "step_mfma_frac": round(ips / world * gflop_img / 1e3 / (PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS), 4) if a.image_size == 256 else None,
-        "losses": {k: round(float(v.detach()), 4) for k, v in losses.items() if v.numel() == 1},
+        # (the FLOP model is the 256x256 full-width one of SURVEY.md §8(d); other configurations report throughput only)
+        "step_gflop_per_image": round(gflop_img, 1) if full else None,
+        "step_tflops": round(tfl, 2) if full else None,   # algorithmic FLOPs of the step / time, per GPU
+        # the whole step (HBM-bound passes included) over the matrix ceiling of the arithmetic its convolutions actually run
+        "step_frac_of_ceiling": round(tfl / ceiling, 4) if full else None,
+        "step_ceiling_tflops": round(ceiling, 1), "step_ceiling_note": ceiling_note,
+        # for orientation only: the f32 MFMA instruction (157.3 TFLOP/s) is what the reference's arithmetic would use on this chip
+        "step_vs_f32_mfma_peak": round(tfl / PEAK_F32_MFMA_TFLOPS, 4) if full else None,
+        "losses": res["losses"],
     }
-    out["vs_rocm_eager"] = vs_rocm_eager(ips, a, world)
-    if a.roofline == "on":
-        del trainer
-        torch.cuda.empty_cache()
-        out["roofline"] = probe(device, a.batch, a.roofline_launches)
-        out["roofline_wgrad"] = roofline_probe_wgrad(device, a.batch, a.roofline_launches, bf16)
-        out["roofline_hbm"] = roofline_probe_hbm(device, a.batch, a.roofline_launches, bf16)
-    if a.cpu_baseline == "auto" and world == 1:
-        out["cpu_baseline"] = cpu_baseline()
-        out["cpu_baseline_config1"] = cpu_baseline_config1()
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

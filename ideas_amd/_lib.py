@@ -76,7 +76,8 @@ _PROTOS = {
     "ideas_conv_wgrad_direct": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_demod": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ideas_weight_sqsum": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_float, _P]),
-    "ideas_demod_bwd": (C.c_int, [_P] * 7 + [C.c_int] * 3 + [_P]),
+    "ideas_weight_sqsum_f64": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_float, _P]),
+    "ideas_demod_bwd": (C.c_int, [_P] * 7 + [C.c_int] * 3 + [C.c_float, _P]),
     "ideas_demod_wgrad": (C.c_int, [_P] * 4 + [C.c_int] * 5 + [C.c_int64] * 8 + [C.c_float, _P]),
     "ideas_pixel_dot": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),
     "ideas_reflect_fold": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -103,7 +104,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.ideas_abi_version() != 1 or lib.ideas_sizeof_conv_params() != C.sizeof(ConvParams):
+    if lib.ideas_abi_version() != 2 or lib.ideas_sizeof_conv_params() != C.sizeof(ConvParams):
         raise RuntimeError("libideas_hip.so ABI mismatch (version or ideas_conv_params layout)")
     _lib = lib
     return lib

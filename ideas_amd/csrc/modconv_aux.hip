@@ -6,6 +6,14 @@
 //                    = sum_i s[b,i]^2 * (scale^2 * sum_k W[o,i,k]^2).
 //   ideas_pixel_dot  out[b,c] += sum_p a[b,p,c] * g[b,p,c] (NHWC): the two per-sample reductions the modconv
 //                    backward needs (d style = <x, dx/s>, d demod = <dy, y/d>).
+//
+// Accuracy (round 3).  The style gradient gs = <x, gx>/s + 2 s sum_o gq wsq is the sum of two terms that largely CANCEL (the
+// demodulated output does not change when s is rescaled), so a relative error eps on either term becomes eps |term| / |gs| on the
+// result -- measured 4x the f32 CPU reference's error on G's modulation weights at 256x256 when the 65 536-pixel dot products
+// and the demodulation algebra ran in f32.  These kernels are HBM-bound (pixel_dot, act_bwd_dot) or tiny (demod_bwd), so wider
+// arithmetic is free: products and sums of the dot products are DOUBLE from the first multiply to the global accumulator
+// (ds_add_f64 / global_atomic_add_f64), and demod_bwd evaluates q = sum_i s^2 wsq, d = (q + eps)^-1/2 and both terms of gs in
+// double from the f32 styles and a double wsq; only gs / gq are rounded to f32, once.
 #include "common.hpp"
 
 namespace {
@@ -24,9 +32,16 @@ __global__ __launch_bounds__(256) void demod_kernel(float* __restrict__ d, const
     if (lane == 0) d[idx] = rsqrtf(acc + eps);
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // wsq[o][i] = scale2 * sum_k W[o][i][k]^2 of a 4-D weight of any strides (one thread per (o, i); the fastest-varying thread
 // index follows the smaller of the two channel strides so the reads coalesce in either memory format).
-__global__ __launch_bounds__(256) void weight_sqsum_kernel(float* __restrict__ wsq, const float* __restrict__ w, int Cout, int Cin,
+template <typename ACC>
+__global__ __launch_bounds__(256) void weight_sqsum_kernel(ACC* __restrict__ wsq, const float* __restrict__ w, int Cout, int Cin,
                                                            int KH, int KW, int64_t so, int64_t si, int64_t sky, int64_t skx,
                                                            float scale2) {
     const int64_t n = (int64_t)Cout * Cin;
@@ -35,41 +50,54 @@ __global__ __launch_bounds__(256) void weight_sqsum_kernel(float* __restrict__ w
     int o, i;
     if (so < si) { o = (int)(t % Cout); i = (int)(t / Cout); } else { i = (int)(t % Cin); o = (int)(t / Cin); }
     const float* p = w + o * so + i * si;
-    float acc = 0.f;
+    ACC acc = 0;
     for (int ky = 0; ky < KH; ++ky)
-        for (int kx = 0; kx < KW; ++kx) { const float v = p[ky * sky + kx * skx]; acc = fmaf(v, v, acc); }
-    wsq[(int64_t)o * Cin + i] = acc * scale2;
+        for (int kx = 0; kx < KW; ++kx) { const ACC v = p[ky * sky + kx * skx]; acc = v * v + acc; }
+    wsq[(int64_t)o * Cin + i] = acc * (ACC)scale2;
 }
 
-// Backward of the demodulation folded into the style gradient.  Inputs: the two per-sample reductions of the conv backward,
-//   dot_s[b,i] = <x, gx>[b,i]  (gx = s * dL/d(s x))        dot_d[b,o] = <gy, y>[b,o]  (y = d * conv)
-// Outputs: gq[b,o] = dL/dq of d = (q + eps)^(-1/2), q[b,o] = sum_i s^2 wsq:  gq = -0.5 * (dot_d / d) * d^3 = -0.5 * dot_d * d^2,
-//          gs[b,i] = (s != 0 ? dot_s / s : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (d, dot_d == NULL: first term only).
-// Grid (ceil(Cin / 256), B); every block recomputes gq[b, :] into LDS (Cout values) and block x == 0 also stores it.
-__global__ __launch_bounds__(256) void demod_bwd_kernel(float* __restrict__ gs, float* __restrict__ gq, const float* __restrict__ dot_s,
-                                                        const float* __restrict__ dot_d, const float* __restrict__ d,
-                                                        const float* __restrict__ s, const float* __restrict__ wsq, int Cin, int Cout) {
-    extern __shared__ float s_gq[];
+// Backward of the demodulation folded into the style gradient, in double.  Inputs: the two per-sample reductions of the conv
+// backward (double accumulators),
+//   dot_s[b,i] = <x, gx>[b,i]  (gx = s * dL/d(s x))        dot_d[b,o] = <gy, y>[b,o]  (y = d32 * conv, d32 = the f32 factor the
+//                                                                                       forward multiplied by)
+// Outputs: gq[b,o] = dL/dq of d = (q + eps)^(-1/2), q[b,o] = sum_i s^2 wsq:  dL/dd = dot_d / d32 (exact for the y that was
+//          computed), dd/dq = -0.5 d^3 with d re-evaluated in double  =>  gq = -0.5 * (dot_d / d32) * d^3;
+//          gs[b,i] = (s != 0 ? dot_s / s : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (d32, dot_d == NULL: first term only).
+// Grid (ceil(Cin / 256), B); every block recomputes gq[b, :] into LDS (Cout doubles: one wave per output channel, lanes over
+// Cin) and block x == 0 also stores it.
+__global__ __launch_bounds__(256) void demod_bwd_kernel(float* __restrict__ gs, float* __restrict__ gq, const double* __restrict__ dot_s,
+                                                        const double* __restrict__ dot_d, const float* __restrict__ d32,
+                                                        const float* __restrict__ s, const double* __restrict__ wsq, int Cin, int Cout,
+                                                        float eps) {
+    extern __shared__ double s_gq[];
     const int b = blockIdx.y;
-    if (d) {
-        for (int o = threadIdx.x; o < Cout; o += 256) {
-            const float dv = d[(int64_t)b * Cout + o];
-            const float q = -0.5f * dot_d[(int64_t)b * Cout + o] * dv * dv;
-            s_gq[o] = q;
-            if (blockIdx.x == 0) gq[(int64_t)b * Cout + o] = q;
+    if (d32) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const float* sp = s + (int64_t)b * Cin;
+        for (int o = wave; o < Cout; o += 4) {
+            const double* wp = wsq + (int64_t)o * Cin;
+            double q = 0.0;
+            for (int i = lane; i < Cin; i += 64) { const double sv = sp[i]; q = fma(sv * sv, wp[i], q); }
+            q = wave_sum_f64(q);
+            if (lane == 0) {
+                const double d2 = 1.0 / (q + (double)eps);
+                const double g = -0.5 * (dot_d[(int64_t)b * Cout + o] / (double)d32[(int64_t)b * Cout + o]) * d2 * sqrt(d2);
+                s_gq[o] = g;
+                if (blockIdx.x == 0) gq[(int64_t)b * Cout + o] = (float)g;
+            }
         }
         __syncthreads();
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= Cin) return;
-    const float sv = s[(int64_t)b * Cin + i];
-    float g = sv != 0.f ? dot_s[(int64_t)b * Cin + i] / sv : 0.f;
-    if (d) {
-        float acc = 0.f;
-        for (int o = 0; o < Cout; ++o) acc = fmaf(s_gq[o], wsq[(int64_t)o * Cin + i], acc);
-        g = fmaf(2.f * sv, acc, g);
+    const double sv = s[(int64_t)b * Cin + i];
+    double g = sv != 0.0 ? dot_s[(int64_t)b * Cin + i] / sv : 0.0;
+    if (d32) {
+        double acc = 0.0;
+        for (int o = 0; o < Cout; ++o) acc = fma(s_gq[o], wsq[(int64_t)o * Cin + i], acc);
+        g = fma(2.0 * sv, acc, g);
     }
-    gs[(int64_t)b * Cin + i] = g;
+    gs[(int64_t)b * Cin + i] = (float)g;
 }
 
 // Weight gradient through the demodulation:  gw[o][i][k] += coef * W[o][i][k] * sum_b gq[b,o] * s[b,i]^2   (coef = 2 scale^2),
@@ -93,29 +121,29 @@ __global__ __launch_bounds__(256) void demod_wgrad_kernel(float* __restrict__ gw
 }
 
 template <typename T, typename V>      // T = element (float / bf16), V = four consecutive elements
-__global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out, const T* __restrict__ a,
+__global__ __launch_bounds__(256) void pixel_dot_kernel(double* __restrict__ out, const T* __restrict__ a,
                                                         const T* __restrict__ g, int64_t P, int C,
                                                         int64_t pix_per_block) {
-    extern __shared__ float s_acc[];
+    extern __shared__ double s_acc[];
     const int b = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) s_acc[c] = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) s_acc[c] = 0.0;
     __syncthreads();
     const T* ab = a + (int64_t)b * P * C;
     const T* gb = g + (int64_t)b * P * C;
     if ((C & 3) == 0) {
         const int C4 = C >> 2;
         auto dot_rows = [&](int c4, int pr, int R) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;
             for (int64_t pp = p0 + pr; pp < p1; pp += R) {
                 const float4 av = to_f4(*reinterpret_cast<const V*>(ab + pp * C + c4 * 4));
                 const float4 gv = to_f4(*reinterpret_cast<const V*>(gb + pp * C + c4 * 4));
-                acc.x = fmaf(av.x, gv.x, acc.x); acc.y = fmaf(av.y, gv.y, acc.y);
-                acc.z = fmaf(av.z, gv.z, acc.z); acc.w = fmaf(av.w, gv.w, acc.w);
+                ax = fma((double)av.x, (double)gv.x, ax); ay = fma((double)av.y, (double)gv.y, ay);
+                az = fma((double)av.z, (double)gv.z, az); aw = fma((double)av.w, (double)gv.w, aw);
             }
-            atomicAdd(&s_acc[c4 * 4 + 0], acc.x); atomicAdd(&s_acc[c4 * 4 + 1], acc.y);
-            atomicAdd(&s_acc[c4 * 4 + 2], acc.z); atomicAdd(&s_acc[c4 * 4 + 3], acc.w);
+            atomicAdd(&s_acc[c4 * 4 + 0], ax); atomicAdd(&s_acc[c4 * 4 + 1], ay);
+            atomicAdd(&s_acc[c4 * 4 + 2], az); atomicAdd(&s_acc[c4 * 4 + 3], aw);
         };
         if (C4 <= 256) {
             // thread = (pixel row pr, channel quad c4): fixed channels per thread, coalesced along C
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out,
         }
     } else {
         for (int64_t i = p0 * C + threadIdx.x; i < p1 * C; i += blockDim.x)
-            atomicAdd(&s_acc[(int)(i % C)], ld1(ab + i) * ld1(gb + i));
+            atomicAdd(&s_acc[(int)(i % C)], (double)ld1(ab + i) * (double)ld1(gb + i));
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&out[(int64_t)b * C + c], s_acc[c]);
@@ -140,21 +168,21 @@ __global__ __launch_bounds__(256) void pixel_dot_kernel(float* __restrict__ out,
 // so the pre-activation tensor never has to be kept for the backward (d(demod) = dot / demod).
 template <typename T, typename V>
 __global__ __launch_bounds__(256) void act_bwd_dot_kernel(T* __restrict__ gpre, float* __restrict__ bgrad,
-                                                          float* __restrict__ dot, const T* __restrict__ gy,
+                                                          double* __restrict__ dot, const T* __restrict__ gy,
                                                           const T* __restrict__ out, const float* __restrict__ bias,
                                                           const float* __restrict__ gscale, int64_t P, int C,
                                                           int64_t pix_per_block, float alpha, float act_gain) {
-    extern __shared__ float s_acc[];   // [2][C]: dot partials, bias-grad partials
+    extern __shared__ double s_acc[];   // [2][C]: dot partials, bias-grad partials (double: see the header of this file)
     const int b = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
     const int64_t p1 = (p0 + pix_per_block < P) ? p0 + pix_per_block : P;
-    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) s_acc[c] = 0.f;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) s_acc[c] = 0.0;
     __syncthreads();
     const int64_t base = (int64_t)b * P * C;
     const int C4 = C >> 2;
     const float inv_gain = 1.0f / act_gain, inv_alpha = 1.0f / alpha;
     auto rows = [&](int c4, int pr, int R) {
-        float4 accd = make_float4(0.f, 0.f, 0.f, 0.f), accb = accd;
+        struct { double x, y, z, w; } accd = {0.0, 0.0, 0.0, 0.0}, accb = {0.0, 0.0, 0.0, 0.0};
         const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         // optional per-(b, c) factor on the stored gradient only (bf16 path: the demodulation d[b,c], so that the input- and
         // weight-gradient kernels need no per-sample input scale); bias_grad / dot are taken before it
@@ -170,8 +198,8 @@ __global__ __launch_bounds__(256) void act_bwd_dot_kernel(T* __restrict__ gpre, 
         gp.f = gsel * act_gain;                                                   \
         const float t = o.f * inv_gain;                                           \
         const float pre = ((t > 0.f) ? t : t * inv_alpha) - bv.f;                 \
-        accd.f = fmaf(gp.f, pre, accd.f);                                         \
-        accb.f += gp.f;                                                           \
+        accd.f = fma((double)gp.f, (double)pre, accd.f);                          \
+        accb.f += (double)gp.f;                                                   \
     }
             ONE(x) ONE(y) ONE(z) ONE(w)
 #undef ONE
@@ -192,7 +220,7 @@ __global__ __launch_bounds__(256) void act_bwd_dot_kernel(T* __restrict__ gpre, 
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         atomicAdd(&dot[(int64_t)b * C + c], s_acc[c]);
-        atomicAdd(&bgrad[c], s_acc[C + c]);
+        atomicAdd(&bgrad[c], (float)s_acc[C + c]);
     }
 }
 
@@ -213,18 +241,28 @@ extern "C" int ideas_weight_sqsum(float* wsq, const float* w, int Cout, int Cin,
     if (!wsq || !w) return IDEAS_E_NULL;
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return IDEAS_E_SHAPE;
     const int64_t n = (int64_t)Cout * Cin;
-    hipLaunchKernelGGL(weight_sqsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsq, w, Cout, Cin, KH,
+    hipLaunchKernelGGL(weight_sqsum_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsq, w, Cout, Cin, KH,
                        KW, so, si, sky, skx, scale2);
     return ideas_launch_status();
 }
 
-extern "C" int ideas_demod_bwd(float* gs, float* gq, const float* dot_s, const float* dot_d, const float* d, const float* s,
-                               const float* wsq, int B, int Cin, int Cout, void* stream) {
+extern "C" int ideas_weight_sqsum_f64(double* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky,
+                                      int64_t skx, float scale2, void* stream) {
+    if (!wsq || !w) return IDEAS_E_NULL;
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return IDEAS_E_SHAPE;
+    const int64_t n = (int64_t)Cout * Cin;
+    hipLaunchKernelGGL(weight_sqsum_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wsq, w, Cout, Cin,
+                       KH, KW, so, si, sky, skx, scale2);
+    return ideas_launch_status();
+}
+
+extern "C" int ideas_demod_bwd(float* gs, float* gq, const double* dot_s, const double* dot_d, const float* d, const float* s,
+                               const double* wsq, int B, int Cin, int Cout, float eps, void* stream) {
     if (!gs || !dot_s || !s) return IDEAS_E_NULL;
     if (d && (!gq || !dot_d || !wsq)) return IDEAS_E_NULL;
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535 || Cout > 16384) return IDEAS_E_SHAPE;
-    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Cin + 255) / 256, B), dim3(256), d ? Cout * sizeof(float) : 0, (hipStream_t)stream, gs, gq,
-                       dot_s, dot_d, d, s, wsq, Cin, Cout);
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535 || Cout > 6144) return IDEAS_E_SHAPE;
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Cin + 255) / 256, B), dim3(256), d ? Cout * sizeof(double) : 0, (hipStream_t)stream, gs, gq,
+                       dot_s, dot_d, d, s, wsq, Cin, Cout, eps);
     return ideas_launch_status();
 }
 
@@ -239,11 +277,11 @@ extern "C" int ideas_demod_wgrad(float* gw, const float* w, const float* gq, con
     return ideas_launch_status();
 }
 
-extern "C" int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, int C, int dtype,
+extern "C" int ideas_pixel_dot(double* out, const void* a, const void* g, int B, int64_t P, int C, int dtype,
                                void* stream) {
     if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!out || !a || !g) return IDEAS_E_NULL;
-    if (B <= 0 || P <= 0 || C <= 0 || C > 12288 || B > 65535) return IDEAS_E_SHAPE;
+    if (B <= 0 || P <= 0 || C <= 0 || C > 6144 || B > 65535) return IDEAS_E_SHAPE;
     if ((C & 3) == 0 && (!ideas_aligned16(a) || !ideas_aligned16(g))) return IDEAS_E_ALIGN;
     if (dtype == IDEAS_BF16 && (C & 3)) return IDEAS_E_ALIGN;
     int64_t chunks = ideas_cdiv(2048, B);
@@ -254,19 +292,19 @@ extern "C" int ideas_pixel_dot(float* out, const void* a, const void* g, int B, 
     chunks = ideas_cdiv(P, per);
     if (dtype == IDEAS_BF16)
         hipLaunchKernelGGL((pixel_dot_kernel<ideas_bf16, ideas_bf16x4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
-                           (size_t)C * sizeof(float), (hipStream_t)stream, out, (const ideas_bf16*)a, (const ideas_bf16*)g, P, C, per);
+                           (size_t)C * sizeof(double), (hipStream_t)stream, out, (const ideas_bf16*)a, (const ideas_bf16*)g, P, C, per);
     else
         hipLaunchKernelGGL((pixel_dot_kernel<float, float4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
-                           (size_t)C * sizeof(float), (hipStream_t)stream, out, (const float*)a, (const float*)g, P, C, per);
+                           (size_t)C * sizeof(double), (hipStream_t)stream, out, (const float*)a, (const float*)g, P, C, per);
     return ideas_launch_status();
 }
 
-extern "C" int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out,
+extern "C" int ideas_act_bwd_dot(void* gpre, float* bias_grad, double* dot, const void* gy, const void* out,
                                  const float* bias, const float* gpre_scale, int B, int64_t P, int C, float alpha,
                                  float act_gain, int dtype, void* stream) {
     if (dtype != IDEAS_F32 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!gpre || !bias_grad || !dot || !gy || !out) return IDEAS_E_NULL;
-    if (B <= 0 || P <= 0 || C <= 0 || C > 6144 || B > 65535) return IDEAS_E_SHAPE;
+    if (B <= 0 || P <= 0 || C <= 0 || C > 3072 || B > 65535) return IDEAS_E_SHAPE;
     if (C & 3) return IDEAS_E_ALIGN;
     if (!ideas_aligned16(gpre) || !ideas_aligned16(gy) || !ideas_aligned16(out) || (bias && !ideas_aligned16(bias)))
         return IDEAS_E_ALIGN;
@@ -278,11 +316,11 @@ extern "C" int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const
     chunks = ideas_cdiv(P, per);
     if (dtype == IDEAS_BF16)
         hipLaunchKernelGGL((act_bwd_dot_kernel<ideas_bf16, ideas_bf16x4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
-                           (size_t)2 * C * sizeof(float), (hipStream_t)stream, (ideas_bf16*)gpre, bias_grad, dot,
+                           (size_t)2 * C * sizeof(double), (hipStream_t)stream, (ideas_bf16*)gpre, bias_grad, dot,
                            (const ideas_bf16*)gy, (const ideas_bf16*)out, bias, gpre_scale, P, C, per, alpha, act_gain);
     else
         hipLaunchKernelGGL((act_bwd_dot_kernel<float, float4>), dim3((unsigned)chunks, (unsigned)B), dim3(256),
-                           (size_t)2 * C * sizeof(float), (hipStream_t)stream, (float*)gpre, bias_grad, dot, (const float*)gy,
+                           (size_t)2 * C * sizeof(double), (hipStream_t)stream, (float*)gpre, bias_grad, dot, (const float*)gy,
                            (const float*)out, bias, gpre_scale, P, C, per, alpha, act_gain);
     return ideas_launch_status();
 }

@@ -65,26 +65,21 @@ class EqualConv2d(nn.Module):
         activation gain / conv gain.  ``resid``: residual branch added in the epilogue (no-grad passes only).
         ``stride``: override (a 1x1 stride-2 conv whose decimation the caller already did in the blur)."""
         pad, refl = (reflect_pad, True) if reflect_pad else (self.padding, False)
-        if stride is not None:
-            saved, self.stride = self.stride, stride
-            try:
-                return self.forward(input, reflect_pad, act, post_gain, resid)
-            finally:
-                self.stride = saved
         if post_blur is not None and (act is None or self.bias is not None or resid is not None or stride is not None):
             raise RuntimeError("post_blur rides on the fused conv + activation path")
+        stride = self.stride if stride is None else stride        # local: the module is never mutated (re-entrant)
         if act is not None and self.bias is None:
-            return conv2d_bias_act(input, self.weight, act.bias, stride=self.stride, padding=pad, reflect=refl,
+            return conv2d_bias_act(input, self.weight, act.bias, stride=stride, padding=pad, reflect=refl,
                                    gain=self.scale, negative_slope=act.negative_slope, scale=act.scale * post_gain,
                                    resid=resid, post_blur=post_blur)
         if act is None:
             if self.bias is not None and post_gain != 1.0:
                 raise RuntimeError("post_gain with a conv bias is not used on this path")
-            return conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl,
+            return conv2d(input, self.weight, self.bias, stride=stride, padding=pad, reflect=refl,
                           gain=self.scale * post_gain, resid=resid)
         if resid is not None:
             raise RuntimeError("resid needs the fused conv + activation path or a bias-free linear conv")
-        out = conv2d(input, self.weight, self.bias, stride=self.stride, padding=pad, reflect=refl, gain=self.scale)
+        out = conv2d(input, self.weight, self.bias, stride=stride, padding=pad, reflect=refl, gain=self.scale)
         return fused_leaky_relu(out, act.bias, act.negative_slope, act.scale * post_gain)
 
     def __repr__(self):

@@ -33,10 +33,10 @@ from .fused_act import fused_leaky_relu
 
 
 def pixel_dot(a: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
-    """out[b,c] = sum over pixels of a[b,c,h,w]*g[b,c,h,w] (both NHWC in memory)."""
+    """out[b,c] = sum over pixels of a[b,c,h,w]*g[b,c,h,w] (both NHWC in memory), a float64 [B,C] (double products and sums)."""
     a, g = _nhwc(a), _nhwc(g)
     b, c, h, w = a.shape
-    out = scratch.zeros((b, c), a.device)          # consumed (divided into a new tensor) before the caller returns
+    out = scratch.zeros((b, c), a.device, torch.float64)          # consumed (divided into a new tensor) before the caller returns
     if a.dtype != g.dtype:
         a, g = a.float(), g.float()
     if a.dtype == torch.bfloat16 and c % 4:
@@ -59,6 +59,18 @@ def weight_sqsum(w: torch.Tensor, scale: float) -> torch.Tensor:
     return conv_plan.cached(w, ("wsq", float(scale)), make)
 
 
+def weight_sqsum_f64(w: torch.Tensor, scale: float) -> torch.Tensor:
+    """The same table in double, for the backward's demodulation algebra (ideas_demod_bwd); memoised like the f32 one."""
+    def make():
+        cout, cin, kh, kw = w.shape
+        wsq = torch.empty((cout, cin), device=w.device, dtype=torch.float64)
+        so, si, sky, skx = w.stride()
+        _lib.check(_lib.load().ideas_weight_sqsum_f64(_lib.ptr(wsq), _lib.ptr(w), cout, cin, kh, kw, so, si, sky, skx, float(scale * scale),
+                                                      _lib.stream_ptr()), "ideas_weight_sqsum_f64")
+        return wsq
+    return conv_plan.cached(w, ("wsq64", float(scale)), make)
+
+
 def demod_raw(s: torch.Tensor, wsq: torch.Tensor, eps: float) -> torch.Tensor:
     """d[b,o] = rsqrt((s*s) @ wsq^T + eps) on the shuffle-reduction kernel (no autograd: the modulated-conv Functions own the
     derivative, _style_grads / _demod_wgrad)."""
@@ -70,20 +82,23 @@ def demod_raw(s: torch.Tensor, wsq: torch.Tensor, eps: float) -> torch.Tensor:
     return d
 
 
-def _style_grads(dot_s, dot_d, s, d, w, gain: float):
-    """(gs, gq) of one modulated conv from its two per-sample reductions: the direct term <x, dL/d(s x)> = dot_s / s and the
-    term through the demodulation d(s, W), in one kernel (ideas_demod_bwd).  gq[b,o] = dL/dq of d = rsqrt(q + eps) is what
-    the weight gradient through the demodulation needs (_demod_wgrad).
+def _style_grads(dot_s, dot_d, s, d, w, gain: float, eps: float = 1e-8):
+    """(gs, gq) of one modulated conv from its two per-sample reductions (float64 [B,Cin] / [B,Cout]): the direct term
+    <x, dL/d(s x)> = dot_s / s and the term through the demodulation d(s, W), in one kernel (ideas_demod_bwd) that works in double
+    -- the two terms cancel to a small remainder.  gq[b,o] = dL/dq of d = rsqrt(q + eps) is what the weight gradient through the
+    demodulation needs (_demod_wgrad).
     Where s == 0 exactly the direct quotient is undefined and 0 is used (the true value needs a second, unscaled
     input-gradient launch; s = affine(style) with bias 1 never hits an exact zero in training — DESIGN.md §5)."""
     b, cin = s.shape
     gs = torch.empty_like(s)
     gq = wsq = None
     cout = w.shape[0]
+    if dot_s.dtype != torch.float64 or (dot_d is not None and dot_d.dtype != torch.float64):
+        raise RuntimeError("_style_grads takes the float64 accumulators of pixel_dot / act_bwd_dot")
     if d is not None:
-        gq, wsq = torch.empty_like(d), weight_sqsum(w, gain)
+        gq, wsq = torch.empty_like(d), weight_sqsum_f64(w, gain)
     rc = _lib.load().ideas_demod_bwd(_lib.ptr(gs), _lib.ptr(gq), _lib.ptr(dot_s), _lib.ptr(dot_d), _lib.ptr(d), _lib.ptr(s),
-                                     _lib.ptr(wsq), b, cin, cout, _lib.stream_ptr())
+                                     _lib.ptr(wsq), b, cin, cout, float(eps), _lib.stream_ptr())
     _lib.check(rc, "ideas_demod_bwd")
     return gs, gq
 
@@ -114,7 +129,7 @@ class _ModConv(Function):
         else:
             g = ConvGeom(k, k, 1, k // 2, False)
             y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d)
-        ctx.g, ctx.up, ctx.gain, ctx.has_d = g, up, gain, d is not None
+        ctx.g, ctx.up, ctx.gain, ctx.has_d, ctx.eps = g, up, gain, d is not None, eps
         ctx.save_for_backward(x, w, s, d if d is not None else s.new_zeros(0), y)
         return y
 
@@ -133,8 +148,8 @@ class _ModConv(Function):
             else:
                 gx = conv_dgrad_raw(gy, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
         if need_s or (need_w and d is not None):
-            dot_s = pixel_dot(x, gx) if need_s else scratch.zeros(tuple(s.shape), s.device)
-            gs, gq = _style_grads(dot_s, pixel_dot(gy, y) if d is not None else None, s, d, w, gain)
+            dot_s = pixel_dot(x, gx) if need_s else scratch.zeros(tuple(s.shape), s.device, torch.float64)
+            gs, gq = _style_grads(dot_s, pixel_dot(gy, y) if d is not None else None, s, d, w, gain, ctx.eps)
         if need_w:
             if ctx.up:
                 wt_shape = (w.shape[1], w.shape[0], w.shape[2], w.shape[3])
@@ -156,7 +171,7 @@ class _ModConv(Function):
 
 
 def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: float, act_gain: float, bias_grad_into=None):
-    """(g_pre, bias_grad[C], dot[B,C]) from the incoming gradient and the saved post-activation output.  ``bias_grad_into``: add
+    """(g_pre, bias_grad[C], dot[B,C] float64) from the incoming gradient and the saved post-activation output.  ``bias_grad_into``: add
     the bias gradient into that f32 [C] buffer (the parameter's .grad) instead of returning a fresh one (returns None for it)."""
     gy, out = _nhwc(gy), _nhwc(out)
     if gy.dtype != out.dtype:
@@ -164,7 +179,7 @@ def act_bwd_dot(gy: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, alpha: 
     b, c, h, w = out.shape
     gpre = torch.empty_like(out)
     bg = bias_grad_into if bias_grad_into is not None else torch.zeros(c, device=out.device, dtype=torch.float32)
-    dot = scratch.zeros((b, c), out.device)
+    dot = scratch.zeros((b, c), out.device, torch.float64)
     rc = _lib.load().ideas_act_bwd_dot(_lib.ptr(gpre), _lib.ptr(bg), _lib.ptr(dot), _lib.ptr(gy), _lib.ptr(out),
                                        _lib.ptr(bias), None, b, h * w, c, float(alpha), float(act_gain), _lib.act_dtype(out),
                                        _lib.stream_ptr())
@@ -186,7 +201,7 @@ class _ModConvAct(Function):
         k = w.shape[2]
         g = ConvGeom(k, k, 1, k // 2, False)
         y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d, bias=b, act=True, act_gain=act_gain, alpha=slope)
-        ctx.g, ctx.gain, ctx.slope, ctx.act_gain = g, gain, slope, act_gain
+        ctx.g, ctx.gain, ctx.slope, ctx.act_gain, ctx.eps = g, gain, slope, act_gain, eps
         ctx.bias_ref = bias_param
         ctx.save_for_backward(x, w, s, d, b, y)
         return y
@@ -203,8 +218,8 @@ class _ModConvAct(Function):
         if need_x or need_s:
             gx = conv_dgrad_raw(gpre, w, g, (x.shape[2], x.shape[3]), gain, lin=d, lout=s)
         if need_s or need_w:
-            dot_s = pixel_dot(x, gx) if need_s else scratch.zeros(tuple(s.shape), s.device)
-            gs, gq = _style_grads(dot_s, dot_d, s, d, w, gain)
+            dot_s = pixel_dot(x, gx) if need_s else scratch.zeros(tuple(s.shape), s.device, torch.float64)
+            gs, gq = _style_grads(dot_s, dot_d, s, d, w, gain, ctx.eps)
         if need_w:
             def grad(out):
                 r = conv_wgrad_raw(gpre, x, g, tuple(w.shape), gain, lin=s, lout=d, out=out)

@@ -25,16 +25,19 @@ def end() -> None:
     _A["on"] = False
 
 
-def zeros(shape, device) -> torch.Tensor:
+def zeros(shape, device, dtype=torch.float32) -> torch.Tensor:
+    """Zeroed float32 (or float64: the double accumulators of ideas_pixel_dot / ideas_act_bwd_dot) buffer of ``shape``."""
     n = 1
     for d in shape:
         n *= d
+    words = n * (2 if dtype == torch.float64 else 1)                 # the arena is counted in 4-byte words
     if not _A["on"] or _A["buf"].device != torch.device(device):
-        return torch.zeros(shape, device=device, dtype=torch.float32)
-    step = -(-n // 64) * 64
+        return torch.zeros(shape, device=device, dtype=dtype)
+    step = -(-words // 64) * 64                                      # 256-byte steps keep every view 8-byte aligned
     if _A["off"] + step > _A["buf"].numel():
         _A["want"] = max(_A["want"], 2 * (_A["off"] + step))        # grow for the next iteration; this call falls back
-        return torch.zeros(shape, device=device, dtype=torch.float32)
-    v = _A["buf"][_A["off"]:_A["off"] + n].view(shape)
+        return torch.zeros(shape, device=device, dtype=dtype)
+    v = _A["buf"][_A["off"]:_A["off"] + words]
+    v = (v.view(torch.float64) if dtype == torch.float64 else v).view(shape)
     _A["off"] += step
     return v

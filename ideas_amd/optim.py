@@ -60,7 +60,8 @@ class FusedAdamEMA(torch.optim.Adam):
         self.flat_g = torch.zeros(n, device=dev)
         self.flat_v = torch.zeros(n, device=dev)
         self.flat_ema = torch.zeros(n, device=dev) if self._ema is not None else None
-        self._steps = 0
+        self._pstep: List[int] = [0] * len(params)      # Adam's per-parameter step count (torch keeps one per tensor)
+        self._index = {id(p): i for i, p in enumerate(params)}
         FLAT_GRADS[id(params[0])] = (self.flat_g, self)
         with torch.no_grad():
             for i, p in enumerate(params):
@@ -95,23 +96,61 @@ class FusedAdamEMA(torch.optim.Adam):
                     p.grad.copy_(stray)
                 self.state[p]["exp_avg"] = p.grad
 
+    @property
+    def _steps(self) -> int:
+        return max(self._pstep)
+
+    @_steps.setter
+    def _steps(self, n: int) -> None:
+        self._pstep = [int(n)] * len(self._params)
+
+    def _span(self, i0: int, i1: int):
+        """[lo, hi) of the flat buffers covered by parameters i0..i1 (inclusive), alignment padding included."""
+        lo = self._off[i0]
+        hi = self._off[i1 + 1] if i1 + 1 < len(self._off) else self.numel
+        return lo, hi
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only: Optional[Sequence[torch.nn.Parameter]] = None):
+        """One launch of ``ideas_adam_ema`` per run of consecutive parameters that share a step count (normally ONE
+        launch for the whole group).  ``only``: the parameters that received a gradient this step — like
+        ``torch.optim.Adam``, which skips parameters whose ``.grad`` is None, the others keep their second moment and
+        step count (stylegan2/train.py:247-270 steps the generator alone after the path-length pass); their EMA copies
+        still take this step's accumulate."""
         self._rebind_grads()
         g = self.param_groups[0]
-        self._steps += 1
         beta2 = g["betas"][1]
-        bc2 = 1.0 - beta2 ** self._steps
-        rc = _lib.load().ideas_adam_ema(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_v),
-                                        _lib.ptr(self.flat_ema), self.flat_p.numel(), float(g["lr"]), float(beta2),
-                                        float(g["eps"]), float(bc2), self.ema_decay, _lib.stream_ptr())
-        _lib.check(rc, "ideas_adam_ema")
+        n = len(self._params)
+        active = [True] * n
+        if only is not None:
+            want = {id(p) for p in only}
+            active = [id(p) in want for p in self._params]
+        lib = _lib.load()
+        i = 0
+        while i < n:
+            j = i
+            while j + 1 < n and active[j + 1] == active[i] and self._pstep[j + 1] == self._pstep[i]:
+                j += 1
+            lo, hi = self._span(i, j)
+            if active[i]:
+                t = self._pstep[i] + 1
+                for k in range(i, j + 1):
+                    self._pstep[k] = t
+                bc2 = 1.0 - beta2 ** t
+                off = 4 * lo
+                rc = lib.ideas_adam_ema(self.flat_p.data_ptr() + off, self.flat_g.data_ptr() + off, self.flat_v.data_ptr() + off,
+                                        None if self.flat_ema is None else self.flat_ema.data_ptr() + off, hi - lo,
+                                        float(g["lr"]), float(beta2), float(g["eps"]), float(bc2), self.ema_decay,
+                                        _lib.stream_ptr())
+                _lib.check(rc, "ideas_adam_ema")
+            elif self.flat_ema is not None and self.ema_decay != 1.0:
+                self.flat_ema[lo:hi].mul_(self.ema_decay).add_(self.flat_p[lo:hi], alpha=1.0 - self.ema_decay)
+            i = j + 1
         return None
 
     def state_dict(self):
-        step = torch.tensor(float(self._steps))
-        for p in self._params:
-            self.state[p]["step"] = step.clone()
+        for p, t in zip(self._params, self._pstep):
+            self.state[p]["step"] = torch.tensor(float(t))
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
@@ -124,7 +163,7 @@ class FusedAdamEMA(torch.optim.Adam):
                     vv.copy_(st["exp_avg_sq"])
                 st["exp_avg_sq"] = vv
                 st["exp_avg"] = p.grad if p.grad is not None else _view_like(self.flat_g, off, p)
-                self._steps = int(float(st.get("step", 0.0)))
+                self._pstep[self._index[id(p)]] = int(float(st.get("step", 0.0)))
 
 
 def fuse_optimizers(trainer, args) -> None:

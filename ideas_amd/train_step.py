@@ -120,7 +120,7 @@ def _params_of(trainer, names) -> List[torch.Tensor]:
     return [p for n in names for p in trainer[n].parameters()]
 
 
-def _step(opt, ema: bool = True) -> None:
+def _step(opt, ema: bool = True, only: Optional[Sequence[torch.Tensor]] = None) -> None:
     """Optimiser step + invalidation of the derived-weight cache (op/conv_plan.py): the fused Adam kernel writes the
     parameters behind autograd's back, so nothing derived from them may outlive it.  ``ema=False``: a FusedAdamEMA step
     that leaves the EMA copies alone (decay 1: ema = 1 * ema + 0 * p) — for iterations that step a group twice."""
@@ -128,7 +128,10 @@ def _step(opt, ema: bool = True) -> None:
     if not ema and decay is not None:
         opt.ema_decay = 1.0
     try:
-        opt.step()
+        if only is not None and hasattr(opt, "_pstep"):
+            opt.step(only=only)       # FusedAdamEMA: leave the parameters without a gradient alone, as torch's Adam does
+        else:
+            opt.step()
     finally:
         if not ema and decay is not None:
             opt.ema_decay = decay
@@ -167,6 +170,24 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
             reducer(tag, params)
         if hook is not None:
             hook(tag, params)
+
+    class _Deferred:
+        """Exchange of one group's gradients launched now and completed later (``finish()`` = wait + test hook +
+        optimiser step): the all-reduce runs on RCCL's stream under whatever is issued in between.  Reducers without
+        ``start`` (or no reducer) make it the plain blocking sequence at ``finish()``."""
+
+        def __init__(self, tag, params, opt, ema=True):
+            self.tag, self.params, self.opt, self.ema = tag, params, opt, ema
+            self.pending = reducer.start(tag, params) if (reducer is not None and hasattr(reducer, "start")) else None
+
+        def finish(self):
+            if self.pending is not None:
+                self.pending.wait()
+            elif reducer is not None:
+                reducer(self.tag, self.params)
+            if hook is not None:
+                hook(self.tag, self.params)
+            _step(self.opt, ema=self.ema)
 
     # ------------------------------------------------------------------ D phase (train.py:48-102)
     share = bool(getattr(args, "share_forward", True))
@@ -213,12 +234,16 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     T["d_optim"].zero_grad()
     with grad_sink(d_params):
         d_total.backward()
-    _sync("d", d_params)
-    _step(T["d_optim"])
+    # The D group's all-reduce starts here; the optimiser step that consumes it is deferred to the first use of a
+    # discriminator: the R1 pass on lazy-regularisation iterations, otherwise the G phase's first Dreal call — so the
+    # 182 MB exchange runs under the Gstru / G forwards of the G phase, which read no discriminator weight.
+    d_step = _Deferred("d", d_params, T["d_optim"])
     del fake_pred, real_pred, d_total, hat_X1, hat_X2, hat_X3
 
     # ------------------------------------------------------------------ lazy R1 (train.py:105-129)
     if iter_idx % args.d_reg_every == 0:
+        d_step.finish()
+        d_step = None
         Xr = X.detach().clone().requires_grad_(True)
         losses["D_real_r1_loss"] = d_r1_loss(T["Dreal"](Xr), Xr)
         r1 = args.real_r1 / 3 * losses["D_real_r1_loss"] * args.d_reg_every
@@ -254,6 +279,9 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     hat_X2 = T["G"](S2, T1)
     hat_X3 = T["G"](S2, T2)
     losses["G_rec_loss"] = F.l1_loss(hat_X1, X)
+    if d_step is not None:
+        d_step.finish()          # discriminators from here on: the reference's order (D step before the G phase, train.py:101-145)
+        d_step = None
     losses["G_real_loss"] = g_nonsaturating_loss(T["Dreal"](torch.cat((hat_X1, hat_X2, hat_X3), 0)))
     losses["E_dist_loss"] = g_nonsaturating_loss(T["Ddist"](T1))
     if args.use_dco:
@@ -282,12 +310,12 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         T["g_optim"].zero_grad()
         with grad_sink(ex_params):
             torch.autograd.backward(losses["Ex_loss"], inputs=ex_params, retain_graph=True)
+        ex_step = _Deferred("ex", ex_params, T["ex_optim"])      # Ex's exchange runs under the G-side backward
         with grad_sink(g_params):
             torch.autograd.backward(loss_total, inputs=g_params)
         _sync("g", g_params)
         _step(T["g_optim"], ema=not path_step)     # one EMA accumulate per iteration
-        _sync("ex", ex_params)
-        _step(T["ex_optim"])
+        ex_step.finish()
     else:
         # The reference's literal schedule (train.py:209-216): Loss_total.backward(retain_graph) -> g step ->
         # Loss_Ex.backward() (a second traversal of Ex -> E -> G -> Gstru) -> ex step.  Its second traversal reads the
@@ -377,7 +405,14 @@ def path_length_step(trainer, args, batch: int, image_size: int, device, Z: Opti
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         reducer("g", all_g)
-    _step(opt)        # carries the iteration's single EMA accumulate (stylegan2/train.py:272 runs it after the regulariser)
+        if not hasattr(opt, "_pstep"):       # torch's Adam: the zero-filled strays must not look like gradients
+            have = {id(p) for p, g in zip(g_params, grads) if g is not None}
+            for p in all_g:
+                if id(p) not in have:
+                    p.grad = None
+    # carries the iteration's single EMA accumulate (stylegan2/train.py:272 runs it after the regulariser); only G's parameters
+    # have a gradient here: E and Gstru keep their Adam state, fused optimiser or not
+    _step(opt, only=[p for p, g in zip(g_params, grads) if g is not None])
     return {"path_loss": penalty.detach(), "path_length": lengths.mean().detach()}
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IDEAS_ABI_VERSION 1
+#define IDEAS_ABI_VERSION 2   /* 2: the per-sample reductions of the modulated-conv backward accumulate in double (round 3) */
 
 enum { IDEAS_NCHW = 0, IDEAS_NHWC = 1 };
 /* `dtype` of the convolution entry points.  Tensors are f32 in HBM for both values.
@@ -247,30 +247,37 @@ int ideas_demod(float* d, const float* s, const float* wsq, int B, int Cin, int 
 /* wsq[o][i] = scale2 * sum_{ky,kx} W[o][i][ky][kx]^2 of a 4-D f32 weight of strides (so, si, sky, skx) (elements). */
 int ideas_weight_sqsum(float* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky, int64_t skx,
                        float scale2, void* stream);
-/* Style gradient of a modulated conv from the per-sample reductions of its backward (ideas_pixel_dot / ideas_act_bwd_dot):
- *   gq[b,o] = -0.5 * dot_d[b,o] * d[b,o]^2                 (dL/dq of d = rsqrt(q + eps); dot_d = <gy, y>, y = d * conv)
+/* The same table accumulated and stored in double (the operand of ideas_demod_bwd). */
+int ideas_weight_sqsum_f64(double* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky,
+                           int64_t skx, float scale2, void* stream);
+/* Style gradient of a modulated conv from the per-sample reductions of its backward (ideas_pixel_dot / ideas_act_bwd_dot), evaluated
+ * in DOUBLE (its two terms cancel to a small remainder; stylegan2/model.py:239-248 gets the same gradient from autograd through the
+ * materialised per-sample weights):
+ *   q[b,o]  = sum_i s[b,i]^2 wsq[o,i],  dt = (q + eps)^(-1/2)                      (re-evaluated here from s and the double wsq)
+ *   gq[b,o] = -0.5 * (dot_d[b,o] / d[b,o]) * dt^3      (dL/dq; dot_d = <gy, y>, y = d * conv with d = the f32 factor of the forward)
  *   gs[b,i] = (s != 0 ? dot_s[b,i] / s[b,i] : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (dot_s = <x, gx>, gx = s * dL/d(s x))
  * d == NULL (no demodulation): only the first term of gs; gq / dot_d / wsq are then unused. */
-int ideas_demod_bwd(float* gs, float* gq, const float* dot_s, const float* dot_d, const float* d, const float* s, const float* wsq,
-                    int B, int Cin, int Cout, void* stream);
+int ideas_demod_bwd(float* gs, float* gq, const double* dot_s, const double* dot_d, const float* d, const float* s, const double* wsq,
+                    int B, int Cin, int Cout, float eps, void* stream);
 /* Weight gradient through the demodulation, ADDED in place:  gw[o][i][k] += coef * W[o][i][k] * sum_b gq[b,o] * s[b,i]^2
  * (coef = 2 * scale^2).  W has strides (so, si, sky, skx), gw strides (go, gi, gky, gkx). */
 int ideas_demod_wgrad(float* gw, const float* w, const float* gq, const float* s, int B, int Cout, int Cin, int KH, int KW, int64_t so,
                       int64_t si, int64_t sky, int64_t skx, int64_t go, int64_t gi, int64_t gky, int64_t gkx, float coef, void* stream);
 
 /* Per-(b,c) sum over pixels of a[b,p,c]*g[b,p,c] (NHWC).  Gives d(style) and d(demod) of the modulated conv
- * without materialising per-sample weights.  out must be ZEROED float[B*C]. */
-int ideas_pixel_dot(float* out, const void* a, const void* g, int B, int64_t P, int C, int dtype, void* stream);
+ * without materialising per-sample weights.  out must be ZEROED double[B*C]: products and sums are double throughout (the kernel is
+ * HBM-bound; see ideas_demod_bwd for why the width matters).  C <= 6144. */
+int ideas_pixel_dot(double* out, const void* a, const void* g, int B, int64_t P, int C, int dtype, void* stream);
 
 /* Backward prologue of a fused (modulated conv + bias + leaky-ReLU), NHWC, C % 4 == 0.  One pass over the incoming
  * gradient gy and the saved POST-activation output `out` [B,P,C]:
  *     gpre      = (out > 0 ? gy : gy*alpha) * act_gain
  *     bias_grad[c] += sum_{b,p} gpre                       (ZEROED float[C])
- *     dot[b,c]     += sum_p gpre * (inverse_act(out) - bias[c])   (ZEROED float[B*C]; = <gpre, demodulated conv output>)
+ *     dot[b,c]     += sum_p gpre * (inverse_act(out) - bias[c])   (ZEROED double[B*C]; = <gpre, demodulated conv output>; C <= 3072)
  * so neither the pre-activation tensor nor a separate bias-gradient / pixel-dot pass is needed.
  * gpre_scale (optional float[B*C]): the STORED gpre is multiplied by it (bias_grad and dot are not) -- the bf16 path passes
  * the demodulation factor here, so its input- and weight-gradient kernels take the already-scaled gradient. */
-int ideas_act_bwd_dot(void* gpre, float* bias_grad, float* dot, const void* gy, const void* out, const float* bias,
+int ideas_act_bwd_dot(void* gpre, float* bias_grad, double* dot, const void* gy, const void* out, const float* bias,
                       const float* gpre_scale, int B, int64_t P, int C, float alpha, float act_gain, int dtype, void* stream);
 
 /* Adjoint of ReflectionPad2d(pad) in NHWC: gx [B,H,W,C] = fold of gpadded [B,H+2pad,W+2pad,C] (mirrored border rows /

@@ -63,6 +63,33 @@ def main():
         return TS.StepDraws(Z_d=Zall[2 * it, sl], T2_d=Tall[2 * it, sl], boxes_d_fake=b[0], boxes_d_real=b[1], boxes_d_ref=b[2],
                             Z_g=Zall[2 * it + 1, sl], T2_g=Tall[2 * it + 1, sl], boxes_g_fake=b[3], boxes_g_ref=b[4])
 
+    # (0) start-up broadcast: rank 1 starts from different weights / EMA copies / Adam state and must end up with rank 0's,
+    #     through the flat buffers of the fused optimisers (train.py's call)
+    from ideas_amd.ddp import broadcast_parameters
+    trb = fresh()
+    opts = [trb[k] for k in ("d_optim", "g_optim", "ex_optim")]
+    if rank == 1:
+        for o in opts:
+            o.flat_p.add_(1.0)
+            o.flat_v.add_(2.0)
+            o._pstep = [5] * len(o._pstep)
+            if o.flat_ema is not None:
+                o.flat_ema.add_(3.0)
+    stray = torch.nn.Linear(3, 2).cuda()                  # a module no fused optimiser covers: the per-parameter branch
+    with torch.no_grad():
+        stray.weight.fill_(float(rank))
+    broadcast_parameters([v for v in trb.values() if isinstance(v, torch.nn.Module)] + [stray], optimizers=opts)
+    ref0 = fresh() if rank == 1 else trb
+    for k in ("d_optim", "g_optim", "ex_optim"):
+        for buf in ("flat_p", "flat_v", "flat_ema"):
+            a, b = getattr(trb[k], buf), getattr(ref0[k], buf)
+            assert (a is None and b is None) or torch.equal(a, b), (k, buf)
+        assert trb[k]._pstep == [0] * len(trb[k]._pstep)
+    assert float(stray.weight.abs().max()) == 0.0
+    w5 = trb["G"].layers[0].conv1.conv.weight              # 5-D (o,ky,kx,i)-ordered parameter, a view of flat_p
+    assert torch.equal(w5, ref0["G"].layers[0].conv1.conv.weight)
+    del trb, ref0, opts
+
     tr = fresh()
     reducer = GradReducer()
     grads = {}

@@ -47,6 +47,24 @@ def _worker(rank, world, port, q):
             p.grad.fill_(float(rank + 1))
         b.all_reduce_mean()
         assert torch.allclose(b.flat, torch.full_like(b.flat, 1.5))
+        # the asynchronous form train_iteration uses around its deferred optimiser steps: nothing may be assumed before wait()
+        for p in params:
+            p.grad.fill_(float(10 * (rank + 1)))
+        pend = b.all_reduce_mean(async_op=True)
+        pend.wait()
+        pend.wait()                                   # idempotent
+        assert torch.allclose(b.flat, torch.full_like(b.flat, 15.0))
+        # start-up broadcast of a parameter that is dense but in no standard memory format (the (o,ky,kx,i)-ordered 5-D modulated
+        # weight): its bytes travel through a 1-D view of the storage
+        from ideas_amd.model import ModulatedConv2d
+        from ideas_amd.ddp import _dense, _dense_storage_view
+        torch.manual_seed(10 + rank)
+        mc = ModulatedConv2d(8, 16, 3, 32)
+        assert not mc.weight.data.is_contiguous() and _dense(mc.weight.data)
+        assert _dense_storage_view(mc.weight.data).data_ptr() == mc.weight.data.data_ptr()
+        broadcast_parameters([mc])
+        torch.manual_seed(10)
+        assert torch.equal(mc.weight.data, ModulatedConv2d(8, 16, 3, 32).weight.data)
 
         # --- 2. two ranks, different shards, one step each == one process on the concatenated batch
         args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=64, batch_size=1,

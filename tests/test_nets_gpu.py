@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import random
 import torch
 
 from conftest import SKETCH_K, Golden, rel_err, sketch
@@ -323,6 +324,44 @@ def test_train_iteration_with_path_length_and_literal_second_backward():
     assert float((after - before).abs().max()) > 0
 
 
+def test_path_length_step_with_fused_optimizers_leaves_e_and_gstru_state_alone():
+    """the lazy path-length step must step G only.  With FusedAdamEMA, E's and Gstru's second moments and step counts
+    after an iteration WITH the regulariser equal those after the same iteration without it; G's moved on by one step."""
+    from ideas_amd import train_step as TS
+    from ideas_amd.models import init_model
+    from ideas_amd.optim import fuse_optimizers
+    res = {}
+    for reg in (0.0, 2.0):
+        args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=64, batch_size=2,
+                               d_reg_every=4, num_iters=10, use_dco=False, path_regularize=reg, g_reg_every=1)
+        torch.manual_seed(3)
+        tr = TS.build_trainer(args, "cpu", init_model)
+        for v in tr.values():
+            if isinstance(v, torch.nn.Module):
+                v.cuda()
+        fuse_optimizers(tr, args)
+        torch.manual_seed(5)
+        random.seed(5)
+        X = (torch.rand(2, 3, 64, 64) * 2 - 1).cuda()
+        TS.train_iteration(tr, args, X, 1)
+        torch.cuda.synchronize()
+        opt = tr["g_optim"]
+        names = [n for n in TS.G_SIDE for _ in tr[n].parameters()]
+        res[reg] = (opt.flat_v.clone(), list(opt._pstep), names, opt)
+    v0, st0, names, opt = res[0.0]
+    v1, st1, _, _ = res[2.0]
+    for i, n in enumerate(names):
+        lo, hi = opt._span(i, i)
+        if n == "G":
+            assert st1[i] == st0[i] + 1 == 2
+        else:
+            assert st1[i] == st0[i] == 1, (n, st0[i], st1[i])
+            # (the two runs differ by the atomics order of the weight-gradient kernels, ~1e-7; a wrongly applied step would have
+            #  decayed the moment by beta2 = 0.99, i.e. 1e-2)
+            assert rel_err(v1[lo:hi], v0[lo:hi]) < 1e-4, n
+    assert any(rel_err(v1[slice(*opt._span(i, i))], v0[slice(*opt._span(i, i))]) > 1e-3 for i, n in enumerate(names) if n == "G")
+
+
 
 @pytest.mark.parametrize("N", [1, 2])
 def test_full_width_chain_vs_oracle(N):
@@ -404,6 +443,31 @@ def test_fused_adam_ema_matches_torch_adam_and_accumulate():
             assert rel_err(b, a) < 2e-6
     for a, b in zip(o_ref.state_dict()["state"].values(), o_fus.state_dict()["state"].values()):
         assert rel_err(b["exp_avg_sq"], a["exp_avg_sq"]) < 2e-6
+    # A step in which only SOME parameters have a gradient (the lazy path-length step touches the generator alone,
+    # stylegan2/train.py:247-270): torch's Adam skips the ones whose .grad is None -- second moment and step count stay -- and the
+    # fused optimiser must do the same (step(only=...)); the EMA accumulate still covers every parameter.  Then a full step again:
+    # the two sets now carry different step counts (different bias corrections) inside one flat buffer.
+    some = [1, 2]
+    for full in (False, True, True):
+        o_ref.zero_grad(set_to_none=True); o_fus.zero_grad()
+        for i, (a, b) in enumerate(zip(ref, fus)):
+            if full or i in some:
+                gsrc = torch.randn_like(a)
+                a.grad = gsrc.clone()
+                b.grad.add_(gsrc)
+        o_ref.step()
+        o_fus.step(only=None if full else [fus[i] for i in some])
+        accumulate(M(ref_ema), M(ref), decay)
+        for a, b in zip(ref, fus):
+            assert rel_err(b, a) < 2e-6
+        for a, b in zip(ref_ema, fus_ema):
+            assert rel_err(b, a) < 2e-6
+    sd_r, sd_f = o_ref.state_dict()["state"], o_fus.state_dict()["state"]
+    assert [float(sd_f[i]["step"]) for i in range(5)] == [float(sd_r[i]["step"]) for i in range(5)] == [7.0, 8.0, 8.0, 7.0, 7.0]
+    for i in range(5):
+        assert rel_err(sd_f[i]["exp_avg_sq"], sd_r[i]["exp_avg_sq"]) < 2e-6
+    o_fus.load_state_dict(o_fus.state_dict())
+    assert o_fus._pstep == [7, 8, 8, 7, 7]
 
 
 def test_step_replay_gpu_with_fused_optimizers():

@@ -58,6 +58,47 @@ def test_small_shard_fails_loudly_instead_of_spinning(tmp_path):
 
 
 @pytest.mark.gpu
+def test_train_cli_two_ranks_bf16_and_uneven_shards(tmp_path):
+    """train.py under torch.distributed.run with two ranks (gloo, both on device 0): start-up broadcast of the fused optimisers'
+    flat buffers (the per-parameter broadcast of the strided 5-D modulated weights fails on RCCL), --precision bf16
+    reaching a real training run, the sharded loader, rank-0 logging/checkpointing; then the all-ranks abort when the shards are
+    too small for one batch (a lone SystemExit would leave the peer hanging in its next collective)."""
+    import socket
+    from PIL import Image
+    rng = np.random.RandomState(2)
+    data_dir = tmp_path / "imgs"
+    data_dir.mkdir()
+    for i in range(8):
+        Image.fromarray(rng.randint(0, 256, size=(64, 64, 3), dtype=np.uint8)).save(data_dir / f"{i:03d}.png")
+
+    def launch(extra, timeout=900):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", IDEAS_BENCH_SHARE_GPU="1",
+                   IDEAS_DIST_BACKEND="gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "train.py"), "--dataset_path", str(data_dir), "--dataset_type", "normal",
+               "--image_size", "64", "--no_dco", "--num_workers", "0", "--log_every", "1", "--show_every", "2", "--d_reg_every", "2",
+               "--channel", "8", "--texture_channel", "128"] + extra
+        return subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=timeout)
+
+    r = launch(["--exp_name", "d0", "--num_iters", "3", "--save_every", "3", "--batch_size", "2", "--precision", "bf16"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    log = (tmp_path / "experiments/d0/training_logs.txt").read_text()
+    assert "[0000003/0000003] Total:" in log and "[Testing 0000002/0000003]" in log
+    assert "nan" not in log.lower()
+    assert (tmp_path / "experiments/d0/checkpoints/3.pt").exists()
+    r = launch(["--exp_name", "d1", "--num_iters", "4", "--save_every", "100", "--batch_size", "2", "--ckpt",
+                str(tmp_path / "experiments/d0/checkpoints/3.pt")])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "[0000004/0000004] Total:" in (tmp_path / "experiments/d1/training_logs.txt").read_text()
+    r = launch(["--exp_name", "d2", "--num_iters", "1", "--batch_size", "8"], timeout=300)     # 4 images per rank < 8
+    assert r.returncode != 0 and "fewer than --batch_size" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
 def test_resume_keeps_adam_state_of_the_fused_optimizers(tmp_path):
     """Save after two iterations, resume into freshly fused optimisers: second moments, step counts, parameters and EMA
     copies survive, and the next iteration is bit-identical to the one the uninterrupted trainer takes."""

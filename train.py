@@ -53,6 +53,9 @@ def main():
     p.add_argument("--num_workers", type=int, default=4)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--path_regularize", type=float, default=0.0, help="stylegan2/train.py's lazy path-length weight (off in IDEAS)")
+    p.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                   help="f32 = the reference's arithmetic (default); bf16 = mixed precision (bf16 activations and MFMA products, f32 "
+                        "accumulation, master weights, gradients and optimiser state: ideas_amd/precision.py, BASELINE.json configs[4])")
     args = p.parse_args()
     args.start_iter = 0
     args.blur_kernel = (1, 3, 3, 1)
@@ -70,9 +73,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend=os.environ.get("IDEAS_DIST_BACKEND", "nccl"), init_method="env://")
+        backend = os.environ.get("IDEAS_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
 
-    from ideas_amd import checkpoint, data as D, train_step as TS
+    from ideas_amd import checkpoint, data as D, precision, train_step as TS
     from ideas_amd.ddp import GradReducer, broadcast_parameters
     from ideas_amd.models import init_model
     from ideas_amd.optim import fuse_optimizers
@@ -82,6 +89,7 @@ def main():
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
 
+    precision.set_activation_dtype(args.precision)
     torch.manual_seed(args.seed)               # identical replicas on every rank
     trainer = TS.build_trainer(args, "cpu", init_model)
     for v in trainer.values():
@@ -96,7 +104,10 @@ def main():
         print("load model:", path, flush=True)
         args.start_iter = checkpoint.load(path, trainer, map_location=device)
     if world > 1:
-        broadcast_parameters([v for v in trainer.values() if isinstance(v, torch.nn.Module)])
+        # rank 0's weights, EMA copies and Adam state (a resumed rank 0 hands all three over): one broadcast per flat buffer of the
+        # fused optimisers -- contiguous by construction, unlike the (o,ky,kx,i)-ordered 5-D modulated weights RCCL would reject
+        broadcast_parameters([v for v in trainer.values() if isinstance(v, torch.nn.Module)],
+                             optimizers=[trainer[k] for k in ("d_optim", "g_optim", "ex_optim")])
     reducer = GradReducer() if world > 1 else None
     random.seed(args.seed + 1000 + rank)       # crops and draws differ per rank, replicas do not
     torch.manual_seed(args.seed + 1000 + rank)
@@ -105,7 +116,17 @@ def main():
     sampler = D.data_sampler(dataset, shuffle=True, rank=rank, world=world, seed=args.seed)
     loader = D.DeviceLoader(dataset, args.batch_size, sampler, device=device, num_workers=args.num_workers,
                             seed=args.seed + rank, drop_last=True)
-    if len(loader) == 0:
+    short = len(loader) == 0
+    if world > 1:
+        # every rank must take the same exit: a rank that left alone would leave the others hanging in their first collective
+        flag = torch.tensor([int(short)], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if bool(flag.item()) and not short:
+            dist.destroy_process_group()
+            raise SystemExit(f"another rank's dataset shard holds fewer than --batch_size {args.batch_size} images; stopping with it")
+    if short:
+        if world > 1:
+            dist.destroy_process_group()
         raise SystemExit(f"dataset shard of rank {rank} has {len(sampler)} images, fewer than --batch_size {args.batch_size}: "
                          "no full batch can be formed (lower --batch_size or add images)")
     if rank == 0:
