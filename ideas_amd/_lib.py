@@ -76,7 +76,7 @@ _PROTOS = {
     "ideas_conv_wgrad_direct": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_demod": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ideas_weight_sqsum": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_float, _P]),
-    "ideas_weight_sqsum_f64": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_float, _P]),
+    "ideas_weight_sqsum_f64": (C.c_int, [_P, _P] + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_double, _P]),
     "ideas_demod_bwd": (C.c_int, [_P] * 7 + [C.c_int] * 3 + [C.c_float, _P]),
     "ideas_demod_wgrad": (C.c_int, [_P] * 4 + [C.c_int] * 5 + [C.c_int64] * 8 + [C.c_float, _P]),
     "ideas_pixel_dot": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_int, _P]),

@@ -29,6 +29,14 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
     m = pack_bf16(ra, rb);
     l = pack_bf16(ra - lo_f32(m), rb - hi_f32(m));   // exact: <= 8 significant bits are left
 }
+// the same from doubles (operands that are sums of f32 values, e.g. Winograd-transformed weights): the residuals are carried in
+// double, so the three planes hold the leading ~26 bits of the EXACT value instead of those of its f32 rounding
+__device__ __forceinline__ void split2d(double a, double b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16((float)a, (float)b);
+    const double ra = a - (double)lo_f32(h), rb = b - (double)hi_f32(h);
+    m = pack_bf16((float)ra, (float)rb);
+    l = pack_bf16((float)(ra - (double)lo_f32(m)), (float)(rb - (double)hi_f32(m)));
+}
 __device__ __forceinline__ Split4 split4(float4 v) {
     Split4 s;
     split2(v.x, v.y, s.p[0].x, s.p[1].x, s.p[2].x);

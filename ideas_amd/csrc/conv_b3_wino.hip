@@ -49,20 +49,27 @@ __global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restri
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int e = 0; e < 4; ++e) wk[kx][e] = w[base + n * sn + ky * sky + kx * skx + (c + e) * sc];
-        float u[4][4];
+        // The transformed weights are the same for every pixel of every sample, so an error in them is a COHERENT error of the
+        // outputs: it does not average out in the backward's sums over 65 536 pixels (weight gradient, style / demodulation dot
+        // products) the way per-pixel rounding does.  Rounding U twice in f32 ((w0 + w2) + w1, 1.2e-7 relative) made G's late-layer
+        // gradients sit 4x further from f64 than stock f32 arithmetic (tests/test_nets_gpu.py::test_full_width_gradients_vs_oracle);
+        // the sums are exact in double, and the three planes are cut from the double: hi + mid + lo = U to ~2^-26.
+        double u[4][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float s = wk[0][e] + wk[2][e];
+            const double s = (double)wk[0][e] + (double)wk[2][e];
             u[0][e] = wk[0][e];
-            u[1][e] = (s + wk[1][e]) * 0.5f;
-            u[2][e] = (s - wk[1][e]) * 0.5f;
+            u[1][e] = (s + (double)wk[1][e]) * 0.5;
+            u[2][e] = (s - (double)wk[1][e]) * 0.5;
             u[3][e] = wk[2][e];
         }
         const int step = (c >> 4) * 3 + ky;
         const int64_t o = ((int64_t)step * N + n) * 4 + ((c & 15) >> 2);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const Split4 s = split4(make_float4(u[v][0], u[v][1], u[v][2], u[v][3]));
+            Split4 s;
+            split2d(u[v][0], u[v][1], s.p[0].x, s.p[1].x, s.p[2].x);
+            split2d(u[v][2], u[v][3], s.p[0].y, s.p[1].y, s.p[2].y);
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) dst[(v * 3 + pl) * plane + o] = s.p[pl];
         }

@@ -43,7 +43,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 template <typename ACC>
 __global__ __launch_bounds__(256) void weight_sqsum_kernel(ACC* __restrict__ wsq, const float* __restrict__ w, int Cout, int Cin,
                                                            int KH, int KW, int64_t so, int64_t si, int64_t sky, int64_t skx,
-                                                           float scale2) {
+                                                           ACC scale2) {
     const int64_t n = (int64_t)Cout * Cin;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void weight_sqsum_kernel(ACC* __restrict__ wsq
     ACC acc = 0;
     for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) { const ACC v = p[ky * sky + kx * skx]; acc = v * v + acc; }
-    wsq[(int64_t)o * Cin + i] = acc * (ACC)scale2;
+    wsq[(int64_t)o * Cin + i] = acc * scale2;
 }
 
 // Backward of the demodulation folded into the style gradient, in double.  Inputs: the two per-sample reductions of the conv
@@ -247,7 +247,7 @@ extern "C" int ideas_weight_sqsum(float* wsq, const float* w, int Cout, int Cin,
 }
 
 extern "C" int ideas_weight_sqsum_f64(double* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky,
-                                      int64_t skx, float scale2, void* stream) {
+                                      int64_t skx, double scale2, void* stream) {
     if (!wsq || !w) return IDEAS_E_NULL;
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return IDEAS_E_SHAPE;
     const int64_t n = (int64_t)Cout * Cin;

@@ -35,9 +35,12 @@ MATH = {"f32": _lib.F32, "b3": _lib.F32_B3}[_os.environ.get("IDEAS_MATH", "b3")]
 
 def wino_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     """[O,3,3,I] (o, ky, kx, ci) -> U [4,O,3,I]: U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2 over kx."""
+    # (sums in double, ONE rounding to f32: the transformed weights are shared by every pixel, so their rounding error is
+    #  coherent across the backward's pixel reductions -- see csrc/conv_b3_wino.hip::wino_split_weights_kernel)
+    w_ohwi = w_ohwi.double()
     w0, w1, w2 = w_ohwi[:, :, 0], w_ohwi[:, :, 1], w_ohwi[:, :, 2]
     s = w0 + w2
-    return torch.stack((w0, (s + w1) * 0.5, (s - w1) * 0.5, w2)).contiguous()
+    return torch.stack((w0, (s + w1) * 0.5, (s - w1) * 0.5, w2)).float().contiguous()
 
 
 def _wino_ok(g: "ConvGeom", cin: int, width: int, fwd: bool = True) -> bool:
@@ -49,6 +52,9 @@ def _wino_ok(g: "ConvGeom", cin: int, width: int, fwd: bool = True) -> bool:
 # Winograd F(2,3) variant of the split-bf16 kernel for the 3x3/s1/p1 layers (csrc/conv_b3_wino.hip); IDEAS_B3_WINO=0 keeps them
 # on the direct split kernel.
 B3_WINO = _os.environ.get("IDEAS_B3_WINO", "1") != "0"
+# (diagnostics) the Winograd kernel for the forward convs only / the input gradients only
+B3_WINO_FWD = _os.environ.get("IDEAS_B3_WINO_FWD", "1") != "0"
+B3_WINO_DGRAD = _os.environ.get("IDEAS_B3_WINO_DGRAD", "1") != "0"
 
 
 def _b3_wino_ok(g: "ConvGeom", cin: int, cout: int, width: int) -> bool:
@@ -199,7 +205,7 @@ def conv_fwd_raw(x, w, g: ConvGeom, gain: float, lin=None, lout=None, bias=None,
     x = _nhwc(x)
     if resid is not None:
         resid = _nhwc(resid)
-    if x.dtype == torch.float32 and _b3_wino_ok(g, x.shape[1], w.shape[0], x.shape[3]):
+    if x.dtype == torch.float32 and B3_WINO_FWD and _b3_wino_ok(g, x.shape[1], w.shape[0], x.shape[3]):
         b, ci, h, wd = x.shape
         co = w.shape[0]
         y = torch.empty((b, co, h, wd), device=x.device, dtype=x.dtype, memory_format=CL)
@@ -247,7 +253,7 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
         _lib.check(rc, "ideas_reflect_fold")
         return gx
     f32 = gy.dtype == torch.float32
-    if f32 and in_hw == (gy.shape[2], gy.shape[3]) and _b3_wino_ok(g, gy.shape[1], w.shape[1], gy.shape[3]):
+    if f32 and B3_WINO_DGRAD and in_hw == (gy.shape[2], gy.shape[3]) and _b3_wino_ok(g, gy.shape[1], w.shape[1], gy.shape[3]):
         b, co, h, wd = gy.shape
         ci = w.shape[1]
         gx = torch.empty((b, ci, h, wd), device=gy.device, dtype=gy.dtype, memory_format=CL)

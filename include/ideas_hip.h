@@ -249,7 +249,7 @@ int ideas_weight_sqsum(float* wsq, const float* w, int Cout, int Cin, int KH, in
                        float scale2, void* stream);
 /* The same table accumulated and stored in double (the operand of ideas_demod_bwd). */
 int ideas_weight_sqsum_f64(double* wsq, const float* w, int Cout, int Cin, int KH, int KW, int64_t so, int64_t si, int64_t sky,
-                           int64_t skx, float scale2, void* stream);
+                           int64_t skx, double scale2, void* stream);
 /* Style gradient of a modulated conv from the per-sample reductions of its backward (ideas_pixel_dot / ideas_act_bwd_dot), evaluated
  * in DOUBLE (its two terms cancel to a small remainder; stylegan2/model.py:239-248 gets the same gradient from autograd through the
  * materialised per-sample weights):
