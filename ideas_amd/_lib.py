@@ -58,6 +58,7 @@ _PROTOS = {
     "ideas_conv_igemm": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_b3_conv_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wgrad_supported": (C.c_int, [C.POINTER(ConvParams)]),
+    "ideas_b3_wgrad3_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wino_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wino_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P]),
     "ideas_b3_split_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),

@@ -94,6 +94,11 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
 // conv_b3_wgrad.hip: weight gradient with the split contraction (arguments validated, ideas_b3_wgrad_supported)
 int ideas_b3_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                    const ideas_conv_params* p, hipStream_t stream);
+// conv_b3_wgrad3.hip: the same for 3x3 kernels, tap-fused with a rolling window (arguments validated, ideas_b3_wgrad3_supported)
+int ideas_b3_wgrad3(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
+                    const ideas_conv_params* p, hipStream_t stream);
+// IDEAS_B3_WGRAD3=0 in the environment keeps every weight gradient on conv_b3_wgrad.hip (A/B measurements)
+bool ideas_b3_wgrad3_enabled();
 // conv_b3_wino.hip: 3x3/s1/p1 Winograd F(2,3) with the split contraction (uplanes from ideas_b3_wino_split_weights)
 int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* in_scale, const float* out_scale,
                       const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);

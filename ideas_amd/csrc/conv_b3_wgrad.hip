@@ -267,6 +267,7 @@ int launch_b3_wgrad_cfg(float* gw, const void* gy, const void* x, const float* i
 
 extern "C" int ideas_b3_wgrad_supported(const ideas_conv_params* p) {
     if (!p) return 0;
+    if (ideas_b3_wgrad3_enabled() && ideas_b3_wgrad3_supported(p)) return 1;     // the tap-fused 3x3 kernel takes it
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
     // (Cout <= 32 and tiny reductions stay on the f32 kernels: half-empty tiles / atomics-dominated there, measured slower;
     //  32 < Cout <= 64 runs a 64 x 192 tile -- all four waves stage, 18 MFMAs per wave and step -- which beats the f32

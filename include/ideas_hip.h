@@ -157,6 +157,9 @@ int ideas_conv_igemm(void* y, const void* x, const void* wmat, const float* in_s
 int ideas_b3_conv_supported(const ideas_conv_params* p);
 int ideas_b3_wgrad_supported(const ideas_conv_params* p);   /* 1 if ideas_conv_wgrad(IDEAS_F32_B3) runs the split kernel; otherwise it
                                                                 runs the IDEAS_F32 kernel (same arguments, same result class) */
+int ideas_b3_wgrad3_supported(const ideas_conv_params* p);  /* 1 if that split weight gradient is the tap-fused 3x3 kernel with a rolling
+                                                                activation window (csrc/conv_b3_wgrad3.hip: 3x3, stride 1 or 2,
+                                                                OW % 16 == 0, Cin % 64 == 0, Cout % 64 == 0); informational */
 int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream);
 /* The same planes read straight from a parameter of any strides: element (n, ty, tx, ci) of the launch's weight matrix is
  * w[n*sn + ty*sty + tx*stx + ci*sc] (floats; w already points at the first element).  Covers the forward matrix of an

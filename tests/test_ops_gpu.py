@@ -759,6 +759,72 @@ def test_b3_kernels_have_the_f32_kernels_error(case):
         assert err[name][0] < 1e-6, err                          # a few f32 ulps of the dot product's scale
         assert err[name][1] <= 1.5 * err["f32"][1] + 1e-9, err  # rms error: same class as the exact-f32 MFMA kernel
 
+WGRAD3_CASES = [
+    # B, Cin, Cout, H, W (of the conv OUTPUT), stride, reflect, scaled
+    (2, 64, 64, 16, 16, 1, False, False),      # one strip, two images in one range: the window is re-primed at the image boundary
+    (3, 128, 64, 32, 48, 1, False, True),      # three strips, modulated (per-sample scales change at image boundaries)
+    (2, 64, 128, 24, 32, 1, True, False),      # mirror padding
+    (5, 64, 64, 16, 16, 2, False, False),      # stride 2 on a (2H+1)-sized input (the Blur -> 3x3/s2 conv of a downsampling block)
+    (2, 128, 128, 32, 32, 2, False, True),     # stride 2, modulated (roles as in the upsampling modulated conv's weight gradient)
+    (1, 192, 64, 64, 64, 1, False, False),     # long ranges cut inside one image (range boundaries are not image boundaries)
+    (7, 64, 64, 16, 32, 1, False, False),      # rows_total = 112 not a multiple of the range length
+]
+
+
+@pytest.mark.parametrize("case", WGRAD3_CASES)
+def test_b3_tap_fused_weight_gradient(case):
+    """conv_b3_wgrad3.hip (3x3, tap-fused, rolling activation window through ds_read_b64_tr_b16) against f64 and against the
+    exact-f32-MFMA weight gradient on the same inputs: suite tolerance, and an rms error within 1.5x of the f32 kernel's (in units
+    of sum |gy*x|): the split contraction is f32-class here as well.  The dispatch really takes the new kernel for these shapes."""
+    import ctypes as C
+    import ideas_amd.op.conv as CV
+    from ideas_amd import _lib
+    from ideas_amd.op.conv_plan import ConvGeom, plan_wgrad
+    B, ci, co, OH, OW, st, refl, scaled = case
+    torch.manual_seed(sum(case[:6]))
+    pd = 1 if st == 1 else 0
+    H, W = (OH, OW) if st == 1 else (2 * OH + 1, 2 * OW + 1)
+    x = torch.randn(B, ci, H, W, dtype=torch.float64) * (torch.rand(B, ci, 1, 1, dtype=torch.float64) * 3 + 0.1)
+    w = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    s = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if scaled else None
+    d = (torch.rand(B, co, dtype=torch.float64) + 0.5) if scaled else None
+    gain = 1.0 / math.sqrt(ci * 9)
+
+    def fwd(xx, ww):
+        xs = xx * s.view(B, ci, 1, 1) if scaled else xx
+        xin = F.pad(xs, [pd] * 4, mode="reflect") if refl else xs
+        yy = F.conv2d(xin, ww * gain, stride=st, padding=0 if refl else pd)
+        return yy * d.view(B, co, 1, 1) if scaled else yy
+    y = fwd(x, w)
+    assert tuple(y.shape[2:]) == (OH, OW)
+    gy = torch.randn_like(y)
+    (gw_ref,) = torch.autograd.grad(y, w, gy)
+    wa = torch.zeros_like(w, requires_grad=True)
+    (gw_abs,) = torch.autograd.grad(fwd(x.abs(), wa), wa, gy.abs())          # sum |gy * x| per weight
+    g = ConvGeom(3, 3, st, pd, refl)
+    p = CV._params(plan_wgrad(x.shape, y.shape, g), gain)
+    # (stride 2 is opt-in -- IDEAS_B3_WGRAD3_S2=1, set by conftest for this module's process -- because it measured slower)
+    assert _lib.load().ideas_b3_wgrad3_supported(C.byref(p)) == 1, case
+    xd, gyd = dev(x.float(), True), dev(gy.float(), True)
+    sd = dev(s.float()) if scaled else None
+    dd = dev(d.float()) if scaled else None
+    err = {}
+    math0 = CV.MATH
+    for name, mode in (("f32", _lib.F32), ("b3", _lib.F32_B3)):
+        CV.MATH = mode
+        try:
+            gw = CV.conv_wgrad_raw(gyd, xd, g, tuple(w.shape), gain, lin=sd, lout=dd)
+            acc = torch.ones(tuple(w.shape), device="cuda").contiguous(memory_format=CL)
+            CV.conv_wgrad_raw(gyd, xd, g, tuple(w.shape), gain, lin=sd, lout=dd, out=acc)       # accumulate into an existing gradient
+        finally:
+            CV.MATH = math0
+        assert rel_err(gw, gw_ref) < GTOL, (name, case, rel_err(gw, gw_ref))
+        assert rel_err(acc - 1, gw_ref) < GTOL, (name, case, "accumulate")
+        e = (gw.double().cpu() - gw_ref).abs() / gw_abs
+        err[name] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    assert err["b3"][0] < 1e-6, err
+    assert err["b3"][1] <= 1.5 * err["f32"][1] + 1e-9, err
+
 
 def test_b3_dispatch_covers_what_it_claims():
     """ideas_b3_conv_supported / ideas_b3_wgrad_supported are the single source of truth for the dispatch: shapes they
