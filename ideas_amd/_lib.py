@@ -56,6 +56,7 @@ _PROTOS = {
     "ideas_blur_fused": (C.c_int, [_P, _P, _P] + [C.c_int] * 8 + [C.c_float, C.c_int, C.c_int, _P, _P, _P, C.c_float, C.c_float,
                                    C.c_int, _P]),
     "ideas_conv_igemm": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
+    "ideas_conv_igemm_multi": (C.c_int, [C.c_int, _P, _P, C.POINTER(C.c_void_p), _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_b3_conv_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wgrad_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_b3_wgrad3_supported": (C.c_int, [C.POINTER(ConvParams)]),

@@ -91,6 +91,8 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 // `wplanes` from ideas_b3_split_weights)
 int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
                  const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);
+int ideas_b3_fwd_multi(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
+                       const ideas_conv_params* ps, hipStream_t stream);
 // conv_b3_wgrad.hip: weight gradient with the split contraction (arguments validated, ideas_b3_wgrad_supported)
 int ideas_b3_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                    const ideas_conv_params* p, hipStream_t stream);

@@ -90,13 +90,13 @@ __global__ __launch_bounds__(256) void split_weights_strided_kernel(uint2* __res
 // forward family
 // ---------------------------------------------------------------------------------------------------------------
 template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
-__global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, const float* __restrict__ x,
-                                                         const void* __restrict__ wplanes,
-                                                         const float* __restrict__ in_scale,
-                                                         const float* __restrict__ out_scale,
-                                                         const float* __restrict__ bias,
-                                                         const float* __restrict__ resid, ideas_conv_params p,
-                                                         int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+__device__ __forceinline__ void conv_b3_body(float* __restrict__ y, const float* __restrict__ x,
+                                             const void* __restrict__ wplanes,
+                                             const float* __restrict__ in_scale,
+                                             const float* __restrict__ out_scale,
+                                             const float* __restrict__ bias,
+                                             const float* __restrict__ resid, const ideas_conv_params& p,
+                                             int tile_m, int tile_n, unsigned x_bytes, unsigned plane_bytes) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
@@ -110,9 +110,6 @@ __global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, 
     const int t = threadIdx.x;
     const int64_t M = (int64_t)p.B * p.OH * p.OW;
     const int K = p.TY * p.TX * p.Cin;
-    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n;
-    const int tile_m = swz / tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -324,6 +321,74 @@ __global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, 
     }
 }
 
+template <int WM, int WN, int MT, int NT, bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 3) void conv_b3_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                         const void* __restrict__ wplanes,
+                                                         const float* __restrict__ in_scale,
+                                                         const float* __restrict__ out_scale,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ resid, ideas_conv_params p,
+                                                         int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    conv_b3_body<WM, WN, MT, NT, SCALE, REFLECT>(y, x, wplanes, in_scale, out_scale, bias, resid, p, swz / tiles_n, swz % tiles_n, x_bytes,
+                                                 plane_bytes);
+}
+
+// Several launches of the family in ONE grid: the output-parity phases of a stride-2 input gradient / transposed conv
+// (op/conv_plan.py::plan_dgrad: 4 / 2 / 2 / 1 taps), which share x, y and the per-sample scales and differ in their geometry and
+// weight planes.  Block order is launch-major, heaviest launch first (the caller's order: 4, 2, 2, 1 taps), each launch's tiles
+// in their own XCD-banded order: the same schedule as back-to-back launches minus the grid ramp and tail of each, which is what
+// the ~16 K-step launches of the small layers consist of (E.texture.1's input gradient: 26 -> 57 TFLOP/s).  Measured alternative
+// that LOST: interleaving the launches' tiles of one image region (shared activation fetch) -- 160 -> 132 TFLOP/s on
+// G.layers.7.conv1, 158 -> 135 on Dreal.1.conv2's input gradient.
+struct B3Multi {
+    ideas_conv_params p[4];
+    const void* w[4];
+    int off[5];          // first block of launch i (off[n] = grid size)
+    int n, tiles_n;
+};
+
+template <int WM, int WN, int MT, int NT, bool SCALE>
+__global__ __launch_bounds__(256, 3) void conv_b3_multi_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                               const float* __restrict__ in_scale,
+                                                               const float* __restrict__ out_scale, B3Multi a, unsigned x_bytes) {
+    const int bid = blockIdx.x;
+    const int which = (bid >= a.off[1] && a.n > 1) + (bid >= a.off[2] && a.n > 2) + (bid >= a.off[3] && a.n > 3);
+    const int swz = xcd_swizzle(bid - a.off[which], a.off[which + 1] - a.off[which]);
+    const int tile_m = swz / a.tiles_n, tile_n = swz - tile_m * a.tiles_n;
+    const ideas_conv_params& p = a.p[which];                          // block-uniform index: scalar loads from the kernel arguments
+    conv_b3_body<WM, WN, MT, NT, SCALE, false>(y, x, a.w[which], in_scale, out_scale, nullptr, nullptr, p, tile_m, tile_n, x_bytes,
+                                               (unsigned)((int64_t)p.TY * p.TX * p.Cin * p.Cout * 2));
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_b3_multi_cfg(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
+                        const ideas_conv_params* ps, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    B3Multi a;
+    a.n = n;
+    a.tiles_n = (int)ideas_cdiv(ps[0].Cout, BN_);
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        a.p[i] = ps[i];
+        a.w[i] = wplanes[i];
+        a.off[i] = (int)blocks;
+        blocks += ideas_cdiv((int64_t)ps[i].B * ps[i].OH * ps[i].OW, BM_) * a.tiles_n;
+        if (blocks > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    }
+    for (int i = n; i < 4; ++i) { a.p[i] = ps[0]; a.w[i] = wplanes[0]; a.off[i] = (int)blocks; }
+    a.off[n] = (int)blocks;
+    a.off[4] = (int)blocks;
+    const unsigned x_bytes = (unsigned)((int64_t)ps[0].B * ps[0].IH * ps[0].IW * ps[0].Cin * 4);
+    if (in_scale)
+        hipLaunchKernelGGL((conv_b3_multi_kernel<WM, WN, MT, NT, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (float*)y,
+                           (const float*)x, in_scale, out_scale, a, x_bytes);
+    else
+        hipLaunchKernelGGL((conv_b3_multi_kernel<WM, WN, MT, NT, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (float*)y,
+                           (const float*)x, in_scale, out_scale, a, x_bytes);
+    return ideas_launch_status();
+}
+
 template <int WM, int WN, int MT, int NT>
 int launch_b3_cfg(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
                   const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
@@ -361,6 +426,15 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
     if (p->Cout > 64) return launch_b3_cfg<2, 2, 2, 2>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);  // 128x128
     if (p->Cout > 32) return launch_b3_cfg<2, 2, 2, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);  // 128x64
     return launch_b3_cfg<4, 1, 1, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);                    // 128x32
+}
+
+// ideas_conv_igemm_multi (conv_igemm.hip validates): n <= 4 launches sharing x / y / scales, dtype IDEAS_F32_B3
+int ideas_b3_fwd_multi(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
+                       const ideas_conv_params* ps, hipStream_t stream) {
+    const int cout = ps[0].Cout;
+    if (cout > 64) return launch_b3_multi_cfg<2, 2, 2, 2>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
+    if (cout > 32) return launch_b3_multi_cfg<2, 2, 2, 1>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
+    return launch_b3_multi_cfg<4, 1, 1, 1>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
 }
 
 extern "C" int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream_) {

@@ -597,6 +597,27 @@ extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const 
     return launch_fwd_cfg<4, 1, 1, 1>(y, x, wmat, in_scale, out_scale, bias, resid, p, stream);                    // 128x32
 }
 
+extern "C" int ideas_conv_igemm_multi(int n, void* y, const void* x, const void* const* wmat, const float* in_scale, const float* out_scale,
+                                      const ideas_conv_params* params, int dtype, void* stream_) {
+    if (dtype != IDEAS_F32_B3) return IDEAS_E_UNSUPPORTED;
+    if (!y || !x || !wmat || !params) return IDEAS_E_NULL;
+    if (n < 1 || n > 4) return IDEAS_E_SHAPE;
+    if (!ideas_aligned16(x) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
+    for (int i = 0; i < n; ++i) {
+        const ideas_conv_params* p = params + i;
+        int rc = check_conv(p);
+        if (rc) return rc;
+        if (!wmat[i]) return IDEAS_E_NULL;
+        if (!ideas_aligned16(wmat[i])) return IDEAS_E_ALIGN;
+        if (!ideas_b3_conv_supported(p) || p->reflect || p->act || p->accumulate) return IDEAS_E_UNSUPPORTED;
+        // one tensor pair: same x, same y, same channel counts
+        if (p->B != params->B || p->IH != params->IH || p->IW != params->IW || p->Cin != params->Cin || p->YH != params->YH ||
+            p->YW != params->YW || p->Cout != params->Cout)
+            return IDEAS_E_SHAPE;
+    }
+    return ideas_b3_fwd_multi(n, y, x, wmat, in_scale, out_scale, params, (hipStream_t)stream_);
+}
+
 extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                                 const ideas_conv_params* p, int dtype, void* stream_) {
     if (dtype != IDEAS_F32 && dtype != IDEAS_F32_B3 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;

@@ -172,6 +172,27 @@ def launch_fwd(y: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scal
     _lib.check(rc, "ideas_conv_igemm" if L.Cin % 4 == 0 else "ideas_conv_direct")
 
 
+B3_MULTI = _os.environ.get("IDEAS_B3_MULTI", "1") != "0"
+
+
+def launch_multi(y: torch.Tensor, x: torch.Tensor, launches, gain: float, in_scale=None, out_scale=None) -> bool:
+    """The output-parity phases of a stride-2 input gradient / transposed conv as ONE grid (ideas_conv_igemm_multi) where the
+    split-bf16 kernel covers all of them; False -> the caller launches them one by one."""
+    n = len(launches)
+    if not B3_MULTI or n < 2 or n > 4 or x.dtype != torch.float32 or MATH != _lib.F32_B3:
+        return False
+    lib = _lib.load()
+    ps = (_lib.ConvParams * n)(*[_params(L, gain) for L in launches])
+    if not all(lib.ideas_b3_conv_supported(C.byref(ps[i])) for i in range(n)):
+        return False
+    planes = [b3_planes(L) for L in launches]
+    ws = (C.c_void_p * n)(*[_lib.ptr(pl) for pl in planes])
+    rc = lib.ideas_conv_igemm_multi(n, _lib.ptr(y), _lib.ptr(x), ws, _lib.ptr(in_scale), _lib.ptr(out_scale), ps, _lib.F32_B3,
+                                    _lib.stream_ptr())
+    _lib.check(rc, "ideas_conv_igemm_multi")
+    return True
+
+
 def launch_wgrad(gw: torch.Tensor, gy: torch.Tensor, x: torch.Tensor, L: Launch, gain: float, in_scale=None,
                  out_scale=None) -> None:
     lib = _lib.load()
@@ -272,8 +293,9 @@ def conv_dgrad_raw(gy, w, g: ConvGeom, in_hw: Tuple[int, int], gain: float, lin=
     gx = torch.empty((b, ci, in_hw[0], in_hw[1]), device=gy.device, dtype=gy.dtype, memory_format=CL)
     if need_zero:
         gx.zero_()
-    for L in launches:
-        launch_fwd(gx, gy, L, gain, lin, lout)
+    if not launch_multi(gx, gy, launches, gain, lin, lout):
+        for L in launches:
+            launch_fwd(gx, gy, L, gain, lin, lout)
     return gx
 
 

@@ -234,6 +234,14 @@ int ideas_b3_wino_wgrad_supported(const ideas_conv_params* p);
 int ideas_wino_wgrad_fold(float* gw, float* gu, int Cout, int Cin, int64_t so, int64_t sky, int64_t skx, int64_t sc, int clear,
                           void* stream);
 
+/* Up to four launches of ideas_conv_igemm(IDEAS_F32_B3) on ONE tensor pair in one grid: the output-parity phases of a stride-2
+ * input gradient / transposed convolution (stylegan2/model.py:250-261, models.py:32-38: the zero-stuffed taps are never multiplied;
+ * 4 / 2 / 2 / 1 taps for a 3x3 kernel).  params[i] and wmat[i] (planes of ideas_b3_split_weights) describe launch i; x, y, the
+ * per-sample scales, B / IH / IW / Cin / YH / YW / Cout are shared; no bias / resid / act / accumulate / reflect.  The launches run
+ * back to back inside one grid, in the order given (put the one with the most taps first): no grid ramp / tail per launch. */
+int ideas_conv_igemm_multi(int n, void* y, const void* x, const void* const* wmat, const float* in_scale, const float* out_scale,
+                           const ideas_conv_params* params, int dtype, void* stream);
+
 /* Generic direct convolution (VALU) with the same parameterisation and epilogue; any Cin/Cout. Used for the
  * handful of tiny-K layers (RGB / N-channel inputs) where the MFMA tile would be empty. */
 /* (dtype IDEAS_F32, or IDEAS_BF16: bf16 x / y / resid / gy with f32 weights, scales, bias and weight gradient) */

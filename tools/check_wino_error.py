@@ -24,10 +24,15 @@ for (b, ci, h, co) in ((1, 128, 128, 128), (1, 512, 32, 512), (1, 64, 128, 128))
         C.MATH, C.B3_WINO, C.WINOGRAD = math, b3w, w
         y = C.conv_fwd_raw(xg, wg, g, gain)
         e = (y.double().cpu() - ref)
-        res.append("%s rms %.2e max %.2e" % (name, float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(e.abs().max() / ref.abs().max())))
+        # signed statistics: a rounding mode that is not round-to-nearest shows up as a mean error (additive: "dc") or as a mean
+        # error along the sign of the result ("shrink"), both of which survive the backward's sums over pixels
+        res.append("%s rms %.2e max %.2e dc %+.2e shrink %+.2e" % (name, float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()),
+                   float(e.abs().max() / ref.abs().max()), float(e.mean() / ref.pow(2).mean().sqrt()),
+                   float((e * ref.sign()).mean() / ref.abs().mean())))
     y32 = F.conv2d(x, wt, padding=1) * gain
     e = y32.double() - ref
-    res.append("cpu f32 rms %.2e max %.2e" % (float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(e.abs().max() / ref.abs().max())))
+    res.append("cpu f32 rms %.2e max %.2e dc %+.2e shrink %+.2e" % (float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(e.abs().max() / ref.abs().max()),
+               float(e.mean() / ref.pow(2).mean().sqrt()), float((e * ref.sign()).mean() / ref.abs().mean())))
     print(f"{ci}->{co} @{h}: " + " | ".join(res), flush=True)
 
 # sign flips of the (pre-activation) output against f64 -- what a leaky-ReLU behind the conv turns into O(1) gradient differences
