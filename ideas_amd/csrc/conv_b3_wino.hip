@@ -377,6 +377,245 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-sharing variant of the 8-wave tile.  The kernel above walks K as (chunk, ky) and stages one input row per step: every
+// input row is fetched, transformed, split and written to LDS three times (once per ky).  Here the block's 64 pair-rows are a
+// 2-D patch of TR output rows x TP column pairs (TR * TP = 64); a K-step is one 16-channel chunk: the TR + 2 input rows of the
+// patch are staged ONCE and the three ky sub-steps read them at row offsets 0, TP, 2 TP (still 32 consecutive LDS rows per MFMA
+// operand, so the conflict-free row swizzle is unchanged).  Per 72 MFMAs of a wave: (TR + 2) / TR instead of 3 stagings per
+// output row (TP = 32: 4 instead of 6 rows per 2 output rows), one barrier instead of 1.5.  Ablations on the kernel above
+// (WINO_ABL): without the window loads +17 %, without transform + split +11 %, without the LDS stores +13 %.
+// Needs H % TR == 0 and (W / 2) % TP == 0; everything else (weights layout, epilogue, wave roles) is the kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SCALE, bool REFLECT, int TP>
+__global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                                const void* __restrict__ uplanes,
+                                                                const float* __restrict__ in_scale,
+                                                                const float* __restrict__ out_scale,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ resid, ideas_conv_params p,
+                                                                int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+    constexpr int TR = WP / TP;                 // output rows of the patch
+    constexpr int SR = (TR + 2) * TP;           // staged pair-rows per chunk
+    constexpr int PL = SR * ROWB;               // bytes per plane
+    constexpr int BN = 2 * WN;                  // channels per block
+    constexpr int BUFB = 12 * PL;
+    constexpr int XB = 2 * 4 * WP * XROW * 4;   // exchange buffer of the epilogue
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB > XB ? 2 * BUFB : XB];
+
+    const int t = threadIdx.x;
+    const int H = p.IH, W = p.IW, W2 = W >> 1;
+    const int tpr = W2 / TP, tpi = (H / TR) * tpr;          // patches per row block, per image
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int pb = tile_m / tpi, prem = tile_m - pb * tpi;
+    const int y0 = (prem / tpr) * TR, px0 = (prem % tpr) * TP;
+    const int n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)uplanes, 0, (int)(12u * plane_bytes), (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)in_scale, 0, SCALE ? p.B * p.Cin * 4 : 0, (int)RSRC_FLAGS);
+
+    // ---- staging: thread = (staged pair-row r, channel quad kq of the chunk); threads past SR * 4 idle in the staging parts ----
+    const int r = t >> 2, kq = t & 3;
+    const bool stager = r < SR;
+    unsigned coff[4], cmask[4], sbase;           // byte offsets of the four window columns; mask = 0xffffffff in the zero padding
+    {
+        const int ir = stager ? r / TP : 0, ptx = r % TP;
+        int iy = y0 - 1 + ir;
+        bool rok = true;
+        if (REFLECT) iy = reflect_coord(iy, H); else rok = iy >= 0 && iy < H;
+        const unsigned rowb = (unsigned)(((pb * H + (rok ? iy : 0)) * W) * p.Cin + kq * 4) * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int ix = 2 * (px0 + ptx) - 1 + j;
+            bool cok = true;
+            if (REFLECT) ix = reflect_coord(ix, W); else cok = ix >= 0 && ix < W;
+            coff[j] = rowb + (unsigned)((cok ? ix : 0) * p.Cin) * 4u;
+            cmask[j] = (rok && cok) ? 0u : 0xffffffffu;
+        }
+        sbase = (unsigned)(pb * p.Cin + kq * 4) * 4u;
+    }
+    const int a_lds = r * ROWB + ((kq * 8) ^ (((r >> 3) & 1) << 4));
+
+    struct Stage { float4 d[4], s; };
+    Stage st0, st1;
+    int k_ci = 0;
+    auto gloadA = [&](Stage& st) {
+        const unsigned so = (unsigned)k_ci * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st.d[j] = buffer_load4(rx, (coff[j] + so) | cmask[j], 0);   // padding: out of range -> zeros
+        if (SCALE) st.s = buffer_load4(rs_, sbase, so);
+        k_ci += BK;
+    };
+    struct Planes { uint2 q[4][3]; };
+    auto transform_split = [&](const Stage& st) {
+        const float4 d0 = st.d[0], d1 = st.d[1], d2 = st.d[2], d3 = st.d[3];
+        float4 v[4];
+        v[0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+        v[1] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+        v[2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+        v[3] = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+        Planes pl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 e = v[c];
+            if (SCALE) e = make_float4(mul_rn(e.x, st.s.x), mul_rn(e.y, st.s.y), mul_rn(e.z, st.s.z), mul_rn(e.w, st.s.w));
+            const Split4 s = split4(e);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pl.q[c][q] = s.p[q];
+        }
+        return pl;
+    };
+    auto lstoreA = [&](int buf, const Planes& pl) {
+        if (SR * 4 < 512 && !stager) return;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(smem + buf * BUFB + (c * 3 + q) * PL + a_lds) = pl.q[c][q];
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wv = wave & 3, wh = wave >> 2;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // operand rows of sub-step ky: a*32 + ky*TP + li; the swizzle bit is bit 3 of that row (TP is a multiple of 8)
+    int f_off[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int row = ky * TP + li;
+        f_off[ky] = (wv * 3) * PL + row * ROWB + ((lh ^ ((row >> 3) & 1)) << 4);
+    }
+    const unsigned fb_voff = (unsigned)((n0 + wh * 64 + li) * 32 + lh * 16) + (unsigned)(wv * 3) * plane_bytes;
+    struct BFrag { bf16x8 f[2][3]; };
+    int b_step = 0;                                       // (chunk * 3 + ky), consumption order
+    auto gloadB = [&](BFrag& fb) {
+        const unsigned soff = (unsigned)(b_step * p.Cout) * 32u;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fb.f[b][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    ru, (int)(fb_voff + (unsigned)pl * plane_bytes + (unsigned)(b * 32 * 32)), (int)soff, 0));
+        ++b_step;
+    };
+    auto mfmas = [&](const bf16x8 (&fa)[2][3], const BFrag& fb) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb.f[b][PB[q]], acc[a][b], 0, 0, 0);
+    };
+    auto afrags = [&](const unsigned char* base, int ky, bf16x8 (&fa)[2][3]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fa[a][pl] = *reinterpret_cast<const bf16x8*>(base + f_off[ky] + pl * PL + a * 32 * ROWB);
+    };
+
+    // chunk c: LDS[c&1] holds its planes, `fbA` the weights of (c, ky 0); chunk c+1's window is in `stg` (transformed + split into
+    // LDS[(c+1)&1] under the first MFMAs), chunk c+2's window is fetched into `ld`; the weights of every sub-step are fetched one
+    // sub-step ahead.  The sets swap roles every chunk (3 sub-steps), so the loop body is two chunks.
+    auto step = [&](int c, Stage& ld, const Stage& stg, BFrag& fbA, BFrag& fbB) {
+        const unsigned char* base = smem + (c & 1) * BUFB;
+        gloadB(fbB);                                       // (c, ky 1): first in the vmcnt queue, wanted soonest
+        gloadA(ld);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            bf16x8 fa[2][3];
+            afrags(base, 0, fa);
+            lstoreA((c & 1) ^ 1, transform_split(stg));
+            mfmas(fa, fbA);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gloadB(fbA);                                       // (c, ky 2)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            bf16x8 fa[2][3];
+            afrags(base, 1, fa);
+            mfmas(fa, fbB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gloadB(fbB);                                       // (c + 1, ky 0)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            bf16x8 fa[2][3];
+            afrags(base, 2, fa);
+            mfmas(fa, fbA);
+        }
+        __syncthreads();
+    };
+    const int nc = p.Cin / BK;
+    BFrag fb0, fb1;
+    gloadA(st0);
+    gloadB(fb0);
+    lstoreA(0, transform_split(st0));
+    gloadA(st1);
+    __syncthreads();
+    int c = 0;
+    for (; c + 1 < nc; c += 2) {
+        step(c, st0, st1, fb0, fb1);
+        step(c + 1, st1, st0, fb1, fb0);
+    }
+    if (c < nc) step(c, st0, st1, fb0, fb1);
+
+    // ---- epilogue: as above; pair-row er of the patch = output row y0 + er / TP, pair px0 + er % TP ------------------------
+    float* exch = reinterpret_cast<float*>(smem);
+    const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;
+    const int64_t opix = (((int64_t)pb * H + y0 + er / TP) * W + 2 * (px0 + er % TP)) * p.Cout;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                exch[((wh * 4 + wv) * WP + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * XROW + li] = acc[a][hb][e];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int cl = cg * 8 + g * 4;
+            const int n = n0 + eh * 64 + hb * 32 + cl;
+            if (n < p.Cout) {
+                const float* ex = exch + (eh * 4 * WP + er) * XROW + cl;
+                const float4 m0v = *reinterpret_cast<const float4*>(ex + 0 * WP * XROW);
+                const float4 m1v = *reinterpret_cast<const float4*>(ex + 1 * WP * XROW);
+                const float4 m2v = *reinterpret_cast<const float4*>(ex + 2 * WP * XROW);
+                const float4 m3v = *reinterpret_cast<const float4*>(ex + 3 * WP * XROW);
+                const float mm[4][4] = {{m0v.x, m0v.y, m0v.z, m0v.w}, {m1v.x, m1v.y, m1v.z, m1v.w},
+                                        {m2v.x, m2v.y, m2v.z, m2v.w}, {m3v.x, m3v.y, m3v.z, m3v.w}};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.Cout) continue;
+                    const float o2[2] = {(mm[0][e] + mm[1][e]) + mm[2][e], (mm[1][e] - mm[2][e]) - mm[3][e]};
+                    const float os = out_scale ? out_scale[(int64_t)pb * p.Cout + n + e] : 1.f;
+                    const float bvv = bias ? bias[n + e] : 0.f;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        float v = mul_rn(o2[px], p.gain);
+                        if (out_scale) v = mul_rn(v, os);
+                        v = mul_then_add(v, 1.0f, bvv);
+                        if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                        const int64_t yi = opix + (int64_t)px * p.Cout + n + e;
+                        if (resid) v = (v + resid[yi]) * p.resid_gain;
+                        if (p.accumulate) y[yi] += v; else y[yi] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int ideas_b3_wino_supported(const ideas_conv_params* p) {
@@ -409,6 +648,27 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
     if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
     const unsigned plane_bytes = (unsigned)((int64_t)3 * p->Cin * p->Cout * 2);     // one (v, plane): 3*Cin/16 steps x Cout x 32 B
+    // row-sharing patch kernel: 8-wave tile shapes whose image divides into TR x TP patches (IDEAS_B3_WINO2D=0: the kernel above)
+    static const bool use2d = [] { const char* e = getenv("IDEAS_B3_WINO2D"); return !(e && e[0] == '0'); }();
+    const int W2 = p->IW / 2;
+    const int TPsel = (W2 % 32 == 0) ? 32 : (W2 % 16 == 0) ? 16 : (W2 % 8 == 0) ? 8 : 0;
+    if (wide && use2d && TPsel && p->IH % (WP / TPsel) == 0 && p->Cin % 16 == 0) {
+        auto go2 = [&](auto sc, auto rf, auto tp) {
+            hipLaunchKernelGGL((conv_b3_wino2d_kernel<decltype(sc)::value, decltype(rf)::value, decltype(tp)::value>),
+                               dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale,
+                               bias, (const float*)resid, *p, tn, x_bytes, plane_bytes);
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        auto go1 = [&](auto tp) {
+            if (in_scale) { if (p->reflect) go2(T{}, T{}, tp); else go2(T{}, F{}, tp); }
+            else { if (p->reflect) go2(F{}, T{}, tp); else go2(F{}, F{}, tp); }
+        };
+        if (TPsel == 32) go1(std::integral_constant<int, 32>{});
+        else if (TPsel == 16) go1(std::integral_constant<int, 16>{});
+        else go1(std::integral_constant<int, 8>{});
+        return ideas_launch_status();
+    }
     auto go = [&](auto sc, auto rf) {
         if (wide)
             hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value, 2>), dim3((unsigned)(tm * tn)),

@@ -705,6 +705,9 @@ B3_CASES = [
     (2, 64, 128, 32, 32, 3, 1, 1, False, False), (2, 128, 72, 16, 16, 3, 1, 1, False, True), (2, 32, 32, 33, 33, 3, 2, 0, False, False),
     (2, 48, 200, 20, 20, 1, 1, 0, False, False), (2, 32, 64, 24, 24, 3, 1, 1, True, False), (1, 512, 512, 8, 8, 3, 1, 1, False, True),
     (3, 16, 16, 7, 12, 3, 1, 1, False, False), (2, 256, 130, 12, 12, 3, 1, 1, False, False),
+    # the row-sharing patch kernel (conv_b3_wino2d_kernel): 2 x 32, 4 x 16 and 8 x 8 patches, mirror padding, modulation, two N tiles
+    (2, 32, 128, 8, 64, 3, 1, 1, True, False), (1, 64, 96, 6, 128, 3, 1, 1, False, True), (2, 32, 160, 16, 32, 3, 1, 1, True, True),
+    (3, 32, 200, 8, 16, 3, 1, 1, False, False),
 ]
 
 
