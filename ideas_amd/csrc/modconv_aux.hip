@@ -63,40 +63,45 @@ __global__ __launch_bounds__(256) void weight_sqsum_kernel(ACC* __restrict__ wsq
 // Outputs: gq[b,o] = dL/dq of d = (q + eps)^(-1/2), q[b,o] = sum_i s^2 wsq:  dL/dd = dot_d / d32 (exact for the y that was
 //          computed), dd/dq = -0.5 d^3 with d re-evaluated in double  =>  gq = -0.5 * (dot_d / d32) * d^3;
 //          gs[b,i] = (s != 0 ? dot_s / s : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (d32, dot_d == NULL: first term only).
-// Grid (ceil(Cin / 256), B); every block recomputes gq[b, :] into LDS (Cout doubles: one wave per output channel, lanes over
-// Cin) and block x == 0 also stores it.
-__global__ __launch_bounds__(256) void demod_bwd_kernel(float* __restrict__ gs, float* __restrict__ gq, const double* __restrict__ dot_s,
-                                                        const double* __restrict__ dot_d, const float* __restrict__ d32,
-                                                        const float* __restrict__ s, const double* __restrict__ wsq, int Cin, int Cout,
-                                                        float eps) {
-    extern __shared__ double s_gq[];
-    const int b = blockIdx.y;
-    if (d32) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const float* sp = s + (int64_t)b * Cin;
-        for (int o = wave; o < Cout; o += 4) {
-            const double* wp = wsq + (int64_t)o * Cin;
-            double q = 0.0;
-            for (int i = lane; i < Cin; i += 64) { const double sv = sp[i]; q = fma(sv * sv, wp[i], q); }
-            q = wave_sum_f64(q);
-            if (lane == 0) {
-                const double d2 = 1.0 / (q + (double)eps);
-                const double g = -0.5 * (dot_d[(int64_t)b * Cout + o] / (double)d32[(int64_t)b * Cout + o]) * d2 * sqrt(d2);
-                s_gq[o] = g;
-                if (blockIdx.x == 0) gq[(int64_t)b * Cout + o] = (float)g;
-            }
-        }
-        __syncthreads();
+// Two launches: demod_gq_kernel, one wave per (b, o), leaves gq in float (for ideas_demod_wgrad) and in double IN PLACE of dot_d;
+// demod_gs_kernel, 64 input channels x 4 slices of the o sum per block, reads the doubles back.  (One kernel with a block per 256
+// input channels that recomputed gq[b, :] itself ran 64 blocks of 1024 serial double steps: 218 us per call, 10.5 ms per iteration.)
+__global__ __launch_bounds__(256) void demod_gq_kernel(float* __restrict__ gq, double* __restrict__ dot_d, const float* __restrict__ d32,
+                                                       const float* __restrict__ s, const double* __restrict__ wsq, int Cin, int Cout,
+                                                       float eps) {
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= Cout) return;
+    const float* sp = s + (int64_t)b * Cin;
+    const double* wp = wsq + (int64_t)o * Cin;
+    double q = 0.0;
+    for (int i = lane; i < Cin; i += 64) { const double sv = sp[i]; q = fma(sv * sv, wp[i], q); }
+    q = wave_sum_f64(q);
+    if (lane == 0) {
+        const double d2 = 1.0 / (q + (double)eps);
+        const double g = -0.5 * (dot_d[(int64_t)b * Cout + o] / (double)d32[(int64_t)b * Cout + o]) * d2 * sqrt(d2);
+        dot_d[(int64_t)b * Cout + o] = g;
+        gq[(int64_t)b * Cout + o] = (float)g;
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Cin) return;
+}
+
+__global__ __launch_bounds__(256) void demod_gs_kernel(float* __restrict__ gs, const double* __restrict__ dot_s,
+                                                       const double* __restrict__ gq64, const float* __restrict__ s,
+                                                       const double* __restrict__ wsq, int Cin, int Cout) {
+    __shared__ double part[4][64];
+    const int b = blockIdx.y, il = threadIdx.x & 63, og = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    double acc = 0.0;
+    if (gq64 && i < Cin) {
+        const double* gp = gq64 + (int64_t)b * Cout;
+        for (int o = og; o < Cout; o += 4) acc = fma(gp[o], wsq[(int64_t)o * Cin + i], acc);
+    }
+    part[og][il] = acc;
+    __syncthreads();
+    if (og != 0 || i >= Cin) return;
     const double sv = s[(int64_t)b * Cin + i];
     double g = sv != 0.0 ? dot_s[(int64_t)b * Cin + i] / sv : 0.0;
-    if (d32) {
-        double acc = 0.0;
-        for (int o = 0; o < Cout; ++o) acc = fma(s_gq[o], wsq[(int64_t)o * Cin + i], acc);
-        g = fma(2.0 * sv, acc, g);
-    }
+    if (gq64) g = fma(2.0 * sv, (part[0][il] + part[1][il]) + (part[2][il] + part[3][il]), g);
     gs[(int64_t)b * Cin + i] = (float)g;
 }
 
@@ -256,13 +261,15 @@ extern "C" int ideas_weight_sqsum_f64(double* wsq, const float* w, int Cout, int
     return ideas_launch_status();
 }
 
-extern "C" int ideas_demod_bwd(float* gs, float* gq, const double* dot_s, const double* dot_d, const float* d, const float* s,
+extern "C" int ideas_demod_bwd(float* gs, float* gq, const double* dot_s, double* dot_d, const float* d, const float* s,
                                const double* wsq, int B, int Cin, int Cout, float eps, void* stream) {
     if (!gs || !dot_s || !s) return IDEAS_E_NULL;
     if (d && (!gq || !dot_d || !wsq)) return IDEAS_E_NULL;
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535 || Cout > 6144) return IDEAS_E_SHAPE;
-    hipLaunchKernelGGL(demod_bwd_kernel, dim3((Cin + 255) / 256, B), dim3(256), d ? Cout * sizeof(double) : 0, (hipStream_t)stream, gs, gq,
-                       dot_s, dot_d, d, s, wsq, Cin, Cout, eps);
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || B > 65535) return IDEAS_E_SHAPE;
+    if (d)
+        hipLaunchKernelGGL(demod_gq_kernel, dim3((Cout + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, gq, dot_d, d, s, wsq, Cin, Cout, eps);
+    hipLaunchKernelGGL(demod_gs_kernel, dim3((Cin + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, gs, dot_s,
+                       d ? (const double*)dot_d : (const double*)nullptr, s, wsq, Cin, Cout);
     return ideas_launch_status();
 }
 

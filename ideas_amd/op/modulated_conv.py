@@ -84,8 +84,8 @@ def demod_raw(s: torch.Tensor, wsq: torch.Tensor, eps: float) -> torch.Tensor:
 
 def _style_grads(dot_s, dot_d, s, d, w, gain: float, eps: float = 1e-8):
     """(gs, gq) of one modulated conv from its two per-sample reductions (float64 [B,Cin] / [B,Cout]): the direct term
-    <x, dL/d(s x)> = dot_s / s and the term through the demodulation d(s, W), in one kernel (ideas_demod_bwd) that works in double
-    -- the two terms cancel to a small remainder.  gq[b,o] = dL/dq of d = rsqrt(q + eps) is what the weight gradient through the
+    <x, dL/d(s x)> = dot_s / s and the term through the demodulation d(s, W), by ideas_demod_bwd, which works in double -- the two
+    terms cancel to a small remainder -- and OVERWRITES dot_d (with gq in double, its own intermediate).  gq[b,o] = dL/dq of d = rsqrt(q + eps) is what the weight gradient through the
     demodulation needs (_demod_wgrad).
     Where s == 0 exactly the direct quotient is undefined and 0 is used (the true value needs a second, unscaled
     input-gradient launch; s = affine(style) with bias 1 never hits an exact zero in training — DESIGN.md §5)."""

@@ -267,8 +267,9 @@ int ideas_weight_sqsum_f64(double* wsq, const float* w, int Cout, int Cin, int K
  *   q[b,o]  = sum_i s[b,i]^2 wsq[o,i],  dt = (q + eps)^(-1/2)                      (re-evaluated here from s and the double wsq)
  *   gq[b,o] = -0.5 * (dot_d[b,o] / d[b,o]) * dt^3      (dL/dq; dot_d = <gy, y>, y = d * conv with d = the f32 factor of the forward)
  *   gs[b,i] = (s != 0 ? dot_s[b,i] / s[b,i] : 0) + 2 s[b,i] * sum_o gq[b,o] * wsq[o,i]      (dot_s = <x, gx>, gx = s * dL/d(s x))
- * d == NULL (no demodulation): only the first term of gs; gq / dot_d / wsq are then unused. */
-int ideas_demod_bwd(float* gs, float* gq, const double* dot_s, const double* dot_d, const float* d, const float* s, const double* wsq,
+ * d == NULL (no demodulation): only the first term of gs; gq / dot_d / wsq are then unused.
+ * dot_d is IN/OUT: on return it holds gq in double (the second launch reads it back; gq is its float copy for ideas_demod_wgrad). */
+int ideas_demod_bwd(float* gs, float* gq, const double* dot_s, double* dot_d, const float* d, const float* s, const double* wsq,
                     int B, int Cin, int Cout, float eps, void* stream);
 /* Weight gradient through the demodulation, ADDED in place:  gw[o][i][k] += coef * W[o][i][k] * sum_b gq[b,o] * s[b,i]^2
  * (coef = 2 * scale^2).  W has strides (so, si, sky, skx), gw strides (go, gi, gky, gkx). */

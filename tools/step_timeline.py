@@ -28,9 +28,11 @@ ev = [e for e in ev if e[0] >= t0]
 span = ev[-1][1] - ev[0][0]
 busy, idle, cur_end = 0, 0, ev[0][0]
 gaps = []
+big = []
 for s, e, n in ev:
     if s > cur_end:
         gaps.append((s - cur_end, prev))
+        big.append((s - cur_end, (cur_end - ev[0][0]) / 1e6, prev, n))
         idle += s - cur_end
         busy += e - s
         cur_end = e
@@ -43,6 +45,9 @@ print("kernels %d  span %.1f ms  busy %.1f ms (%.1f %%)  idle %.1f ms (%.1f %%)"
 for lim in (5, 10, 20, 50, 100, 1000):
     sel = [g for g, _ in gaps if g > lim * 1000]
     print("  gaps > %4d us: %6d  total %.1f ms" % (lim, len(sel), sum(sel) / 1e6))
+print("largest gaps (us, at ms, after -> before):")
+for g, at, a, b in sorted(big, reverse=True)[:14]:
+    print("  %8.1f us at %8.2f ms  %s -> %s" % (g / 1e3, at, short(a)[:60], short(b)[:60]))
 by = collections.Counter()
 for g, n in gaps:
     by[short(n)] += g
