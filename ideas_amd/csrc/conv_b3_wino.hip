@@ -649,7 +649,8 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
     const unsigned plane_bytes = (unsigned)((int64_t)3 * p->Cin * p->Cout * 2);     // one (v, plane): 3*Cin/16 steps x Cout x 32 B
     // row-sharing patch kernel: 8-wave tile shapes whose image divides into TR x TP patches (IDEAS_B3_WINO2D=0: the kernel above)
-    static const bool use2d = [] { const char* e = getenv("IDEAS_B3_WINO2D"); return !(e && e[0] == '0'); }();
+    const char* e2d = getenv("IDEAS_B3_WINO2D");           // read per call: tests toggle it in-process
+    const bool use2d = !(e2d && e2d[0] == '0');
     const int W2 = p->IW / 2;
     const int TPsel = (W2 % 32 == 0) ? 32 : (W2 % 16 == 0) ? 16 : (W2 % 8 == 0) ? 8 : 0;
     if (wide && use2d && TPsel && p->IH % (WP / TPsel) == 0 && p->Cin % 16 == 0) {

@@ -597,7 +597,7 @@ def test_full_width_gradients_vs_oracle(name, monkeypatch):
     weights): the ratio gpu / f32-oracle per tensor measured 0.3, 1.0, 1.1, 1.5, 2.2, 4.2, 5.2, 8.5 and 2800 (a case where the f32
     oracle had no flip at all and sat at 2.6e-6) on different seeds of the SAME build.  A per-tensor ratio on one case is therefore
     a lottery ticket, not a measurement of kernel quality; the flip-free measurement is test_full_width_gradients_near_linear
-    below (same networks, same kernels, activation slope 0.999), which holds the kernels to 3x the f32 oracle.  Here the bar is the
+    below (same networks, same kernels, activation slope 0.9999), which holds the kernels to 3x the f32 oracle.  Here the bar is the
     error class: per tensor, L2 <= max(1e-4, 6 x f32 oracle) and max-abs <= max(1e-4 max|ref|, 12 x) on at least one of up to three
     independent seeded cases, and never worse than 2e-2 (no flip moves a tensor that far; a wrong kernel does)."""
     def over(r):
@@ -621,9 +621,9 @@ def test_full_width_gradients_vs_oracle(name, monkeypatch):
 
 @pytest.mark.parametrize("name", ["E", "G", "Dreal", "Dco"])
 def test_full_width_gradients_near_linear(name, monkeypatch):
-    """The same full-width comparison with the flips taken out: every leaky-ReLU runs with slope 0.999 on both sides (module
+    """The same full-width comparison with the flips taken out: every leaky-ReLU runs with slope 0.9999 on both sides (module
     attribute on the GPU networks, default argument of the oracle's function), so a pre-activation on the wrong side of zero changes
-    the gradient by 0.1 % of one element instead of 80 %, while every kernel of the path -- Winograd / direct / transposed convs, the
+    the gradient by 0.01 % of one element instead of 80 %, while every kernel of the path -- Winograd / direct / transposed convs, the
     tap-fused weight gradient, demodulation, blur, the fused activation backward with its slope-dependent inverse -- runs at the
     bench's shapes.  What is left is kernel arithmetic, and the bar is tight: per tensor L2 <= max(5e-5, 3 x the f32 CPU oracle's),
     max-abs <= max(5e-5 max|ref|, 6 x).
@@ -633,10 +633,13 @@ def test_full_width_gradients_near_linear(name, monkeypatch):
     -1.4e-10 of the accumulator's scale per instruction (tools/check_wino_error.py: mean signed error -6e-8 .. -2e-7 of the output
     rms for the split-bf16 kernels at K = 1152 .. 4608, +-3e-10 for the f32-MFMA kernels and the CPU), i.e. a coherent offset of
     1e-7 that per-pixel statistics never see.  With IDEAS_MATH=f32 IDEAS_WINOGRAD=0 the same tensors sit at 3-6e-6.  The 5e-5 floor
-    is that effect with a factor 2 of room; DESIGN.md section 4 discusses it."""
+    is that effect with a factor 2 of room; DESIGN.md section 4 discusses it.
+    (Slope 0.999 was not flat enough: ONE flipped element in Dco's 2x2x768 layer -- channel 723 of encoder.6.conv1, which the
+    row-sharing Winograd kernel's different summation order upstream moved across zero -- shifted that bias gradient by 3.9e-5 of
+    0.378 = 1.0e-4 in L2 and everything upstream with it (tools/probes/dco_grad_ab.py); at 0.9999 a flip is worth 1e-5.)"""
     import oracle.torch_ref as O
     import ideas_amd.op.fused_act as FA
-    slope = 0.999
+    slope = 0.9999
     monkeypatch.setattr(O.fused_leaky_relu, "__defaults__", (slope, 2 ** 0.5))
     monkeypatch.setattr(FA.fused_leaky_relu, "__defaults__", (slope, 2 ** 0.5))
     res = _full_width_grad_errors(name, prepare=lambda net: _set_slope(net, slope))
