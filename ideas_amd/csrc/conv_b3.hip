@@ -432,6 +432,14 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
 int ideas_b3_fwd_multi(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
                        const ideas_conv_params* ps, hipStream_t stream) {
     const int cout = ps[0].Cout;
+    ideas_conv_params strips[4];
+    const void* strip_w[4];
+    int nstrips = 0;
+    const int rc = ideas_b3_fwd_tphase(n, y, x, wplanes, in_scale, out_scale, ps, stream, strips, strip_w, &nstrips);   // conv_b3_tphase.hip
+    if (rc >= 0) {                                        // (-1 = not its geometry)
+        if (rc != IDEAS_OK || nstrips == 0) return rc;
+        n = nstrips; ps = strips; wplanes = strip_w;      // the last row / column of positions: generic kernel, one grid
+    }
     if (cout > 64) return launch_b3_multi_cfg<2, 2, 2, 2>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
     if (cout > 32) return launch_b3_multi_cfg<2, 2, 2, 1>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
     return launch_b3_multi_cfg<4, 1, 1, 1>(n, y, x, wplanes, in_scale, out_scale, ps, stream);

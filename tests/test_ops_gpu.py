@@ -222,6 +222,7 @@ CONV_CASES = [
     (2, 32, 64, 3, 1, 1, True, 16, 16), (2, 8, 8, 3, 1, 1, True, 4, 4), (1, 256, 256, 3, 1, 1, False, 8, 8),
     (2, 128, 3, 1, 1, 0, False, 32, 32), (2, 3, 32, 1, 1, 0, False, 20, 20), (2, 32, 1, 1, 1, 0, False, 4, 4),
     (2, 1, 32, 1, 1, 0, False, 4, 4), (2, 512, 8, 1, 1, 0, False, 16, 16), (5, 20, 36, 3, 2, 0, False, 17, 17),
+    (2, 128, 64, 3, 2, 0, False, 35, 19),       # its input gradient (128 channels out) runs conv_b3_tphase_kernel
 ]
 
 
@@ -246,7 +247,9 @@ def test_conv_random_vs_oracle(ops, case):
     assert rel_err(gwd, gw) < GTOL, ("gw", case, rel_err(gwd, gw))
 
 
-@pytest.mark.parametrize("case", [(2, 16, 24, 1, 2, 7, 7), (2, 64, 32, 1, 2, 16, 16), (2, 32, 48, 3, 2, 9, 9), (1, 8, 8, 3, 1, 5, 5)])
+@pytest.mark.parametrize("case", [(2, 16, 24, 1, 2, 7, 7), (2, 64, 32, 1, 2, 16, 16), (2, 32, 48, 3, 2, 9, 9), (1, 8, 8, 3, 1, 5, 5),
+                                  # conv_b3_tphase_kernel (Cout > 64): partial patches in both directions, two N tiles, one full patch
+                                  (2, 48, 128, 3, 2, 9, 20), (1, 32, 200, 3, 2, 17, 33), (3, 64, 96, 3, 2, 8, 16)])
 def test_conv_transpose_random_vs_oracle(ops, case):
     B, ci, co, k, s, H, W = case
     torch.manual_seed(sum(case))
@@ -761,6 +764,34 @@ def test_b3_kernels_have_the_f32_kernels_error(case):
     for name in ("b3", "b3w"):
         assert err[name][0] < 1e-6, err                          # a few f32 ulps of the dot product's scale
         assert err[name][1] <= 1.5 * err["f32"][1] + 1e-9, err  # rms error: same class as the exact-f32 MFMA kernel
+
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, 16, True), (3, 32, 160, 7, 21, True), (2, 96, 128, 24, 8, False)])
+def test_b3_transposed_phases_one_pass(case, monkeypatch):
+    """conv_b3_tphase_kernel (the four output-parity phases of a 3x3 / stride-2 transposed conv from one LDS image of the input)
+    against f64 and against conv_b3_multi_kernel (IDEAS_B3_TPHASE=0) on the same operands, plain and modulated."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom, convT_out_size
+    B, ci, co, H, W, mod = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    wt = torch.randn(ci, co, 3, 3, dtype=torch.float64)
+    s = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if mod else None
+    d = (torch.rand(B, co, dtype=torch.float64) + 0.5) if mod else None
+    gain = 1 / math.sqrt(ci * 9)
+    ref = F.conv_transpose2d(x * s.view(B, ci, 1, 1) if mod else x, wt * gain, stride=2)
+    if mod:
+        ref = ref * d.view(B, co, 1, 1)
+    g = ConvGeom(3, 3, 2, 0, False)
+    oh, ow = convT_out_size(H, W, g)
+    xd, wd = dev(x.float(), True), dev(wt.float(), True)
+    sd, dd = (dev(s.float()), dev(d.float())) if mod else (None, None)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_B3_TPHASE", flag)
+        got[flag] = CV.conv_dgrad_raw(xd, wd, g, (oh, ow), gain, sd, dd)
+        assert rel_err(got[flag], ref) < TOL, (flag, case, rel_err(got[flag], ref))
+    assert rel_err(got["1"], got["0"]) < 2e-6
+
 
 WGRAD3_CASES = [
     # B, Cin, Cout, H, W (of the conv OUTPUT), stride, reflect, scaled
