@@ -87,6 +87,26 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
     return a * b;
 }
 
+// ---- batched weight preparation (ideas_weight_prep_batched): one launch per derived form over a table of parameters -----------
+// The derived weights (split-bf16 planes, Winograd planes, bf16 packs) are remade after every optimiser step, one small launch
+// per parameter and form: ~390 launches of 5-25 us per iteration, most of them too small to fill the chip.  The table-driven
+// kernels run the same per-element bodies as the single-tensor kernels (bitwise the same results) over all of a group's parameters.
+__device__ __forceinline__ const ideas_prep_desc* prep_lookup(const ideas_prep_desc* tbl, int n, int& local, int& nblk) {
+    int lo = 0, hi = n - 1;                        // block-uniform binary search over the first-block prefix
+    const int b = (int)blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tbl[mid].block0 <= b) lo = mid; else hi = mid - 1;
+    }
+    local = b - tbl[lo].block0;
+    nblk = tbl[lo].nblocks;
+    return tbl + lo;
+}
+// per-form launchers (conv_b3.hip / conv_b3_wino.hip / conv_bf16.hip)
+void ideas_b3_split_batched(const ideas_prep_desc* tbl, int n, int blocks, hipStream_t stream);
+void ideas_b3_wino_split_batched(const ideas_prep_desc* tbl, int n, int blocks, hipStream_t stream);
+void ideas_bf16_pack_batched(const ideas_prep_desc* tbl, int n, int blocks, hipStream_t stream);
+
 // conv_b3.hip: forward-family implicit GEMM with the bf16x3 split contraction (arguments already validated;
 // `wplanes` from ideas_b3_split_weights)
 int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,

@@ -58,13 +58,13 @@ __global__ __launch_bounds__(256) void split_weights_kernel(uint2* __restrict__ 
 // The same planes read straight from the parameter: element (n, ty, tx, ci) of the launch's matrix at
 // w[n*sn + ty*sty + tx*stx + ci*sc] (see ideas_bf16_pack_weights_strided, conv_bf16.hip).
 template <bool UNIT>
-__global__ __launch_bounds__(256) void split_weights_strided_kernel(uint2* __restrict__ dst, const float* __restrict__ w, int Cout,
-                                                                    int TY, int TX, int Cin, int64_t sn, int64_t sty, int64_t stx,
-                                                                    int64_t sc) {
+__device__ __forceinline__ void split_weights_strided_body(uint2* __restrict__ dst, const float* __restrict__ w, int Cout, int TY, int TX,
+                                                           int Cin, int64_t sn, int64_t sty, int64_t stx, int64_t sc, int64_t bid,
+                                                           int64_t nblk) {
     const int c4 = Cin / 4, ntaps = TY * TX;
     const int64_t n4 = (int64_t)Cout * ntaps * c4;
     const int64_t plane = n4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bid * 256 + threadIdx.x; i < n4; i += nblk * 256) {
         int n, tap, ci;
         if (UNIT) {
             ci = (int)(i % c4) * 4;
@@ -84,6 +84,20 @@ __global__ __launch_bounds__(256) void split_weights_strided_kernel(uint2* __res
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) dst[pl * plane + o] = s.p[pl];
     }
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(256) void split_weights_strided_kernel(uint2* __restrict__ dst, const float* __restrict__ w, int Cout,
+                                                                    int TY, int TX, int Cin, int64_t sn, int64_t sty, int64_t stx,
+                                                                    int64_t sc) {
+    split_weights_strided_body<UNIT>(dst, w, Cout, TY, TX, Cin, sn, sty, stx, sc, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void split_weights_batched_kernel(const ideas_prep_desc* __restrict__ tbl, int n) {
+    int local, nblk;
+    const ideas_prep_desc* d = prep_lookup(tbl, n, local, nblk);
+    if (d->unit) split_weights_strided_body<true>((uint2*)d->dst, d->w, d->a[0], d->a[1], d->a[2], d->a[3], d->s[0], d->s[1], d->s[2], d->s[3], local, nblk);
+    else split_weights_strided_body<false>((uint2*)d->dst, d->w, d->a[0], d->a[1], d->a[2], d->a[3], d->s[0], d->s[1], d->s[2], d->s[3], local, nblk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -443,6 +457,10 @@ int ideas_b3_fwd_multi(int n, void* y, const void* x, const void* const* wplanes
     if (cout > 64) return launch_b3_multi_cfg<2, 2, 2, 2>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
     if (cout > 32) return launch_b3_multi_cfg<2, 2, 2, 1>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
     return launch_b3_multi_cfg<4, 1, 1, 1>(n, y, x, wplanes, in_scale, out_scale, ps, stream);
+}
+
+void ideas_b3_split_batched(const ideas_prep_desc* tbl, int n, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(split_weights_batched_kernel, dim3(blocks), dim3(256), 0, stream, tbl, n);
 }
 
 extern "C" int ideas_b3_split_weights(void* planes, const void* wmat, int Cout, int K, int Cin, void* stream_) {

@@ -38,12 +38,12 @@ constexpr int XROW = 36;          // floats per row of the exchange buffer (32 +
 //   forward : n = o, c = i on the OHWI parameter          (sn = 9I, sky = 3I, skx = I, sc = 1, base = 0)
 //   dgrad   : n = i, c = o, taps flipped, same parameter  (sn = 1, sky = -3I, skx = -I, sc = 9I, base = 8I)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restrict__ dst, const float* __restrict__ w, int N, int C,
-                                                                 int64_t sn, int64_t sky, int64_t skx, int64_t sc, int64_t base) {
+__device__ __forceinline__ void wino_split_weights_body(uint2* __restrict__ dst, const float* __restrict__ w, int N, int C, int64_t sn,
+                                                        int64_t sky, int64_t skx, int64_t sc, int64_t base, int64_t bid, int64_t nblk) {
     const int64_t total = (int64_t)N * 3 * (C / 4);
     const int nsteps = 3 * (C / 16);
     const int64_t plane = (int64_t)nsteps * N * 4;        // uint2 units per (v, plane)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bid * 256 + threadIdx.x; i < total; i += nblk * 256) {
         const int c = (int)(i % (C / 4)) * 4;
         const int ky = (int)((i / (C / 4)) % 3);
         const int n = (int)(i / (3 * (C / 4)));
@@ -77,6 +77,17 @@ __global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restri
             for (int pl = 0; pl < 3; ++pl) dst[(v * 3 + pl) * plane + o] = s.p[pl];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wino_split_weights_kernel(uint2* __restrict__ dst, const float* __restrict__ w, int N, int C,
+                                                                 int64_t sn, int64_t sky, int64_t skx, int64_t sc, int64_t base) {
+    wino_split_weights_body(dst, w, N, C, sn, sky, skx, sc, base, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void wino_split_weights_batched_kernel(const ideas_prep_desc* __restrict__ tbl, int n) {
+    int local, nblk;
+    const ideas_prep_desc* d = prep_lookup(tbl, n, local, nblk);
+    wino_split_weights_body((uint2*)d->dst, d->w, d->a[0], d->a[1], d->s[0], d->s[1], d->s[2], d->s[3], d->s[4], local, nblk);
 }
 
 // NH = 1: 256 threads, tile 64 pairs x  64 channels, K-step 16 channels (4 waves  = the 4 Winograd components)
@@ -624,6 +635,10 @@ extern "C" int ideas_b3_wino_supported(const ideas_conv_params* p) {
            p->OH == p->IH && p->OW == p->IW && p->YH == p->IH && p->YW == p->IW && p->osy == 1 && p->osx == 1 && p->ooy == 0 &&
            p->oox == 0 && (p->IW & 1) == 0 && p->Cin % 16 == 0 && (!p->reflect || (p->IH >= 2 && p->IW >= 2)) &&
            (int64_t)p->B * p->IH * p->IW * p->Cin * 4 < 0xffffffffLL && (int64_t)p->Cin * p->Cout * 72 < 0xffffffffLL;
+}
+
+void ideas_b3_wino_split_batched(const ideas_prep_desc* tbl, int n, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(wino_split_weights_batched_kernel, dim3(blocks), dim3(256), 0, stream, tbl, n);
 }
 
 extern "C" int ideas_b3_wino_split_weights(void* planes, const void* w, int N, int C, int64_t sn, int64_t sky, int64_t skx,

@@ -90,15 +90,14 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(uint4* __restrict__ d
 // phase-sliced transposed matrix of an input gradient, or the matrix of a transposed conv -- so no permuted / sliced f32 copy is
 // materialised first (one launch instead of copy + pack, and 2-4 launches fewer per conv and step than torch's slicing).
 template <bool UNIT>
-__global__ __launch_bounds__(256) void pack_weights_strided_kernel(uint4* __restrict__ dst, const float* __restrict__ w,
-                                                                   const float* __restrict__ scale, int Cout, int TY, int TX, int Cin,
-                                                                   int64_t sn, int64_t sty, int64_t stx, int64_t sc) {
+__device__ __forceinline__ void pack_weights_strided_body(uint4* __restrict__ dst, const float* __restrict__ w,
+                                                          const float* __restrict__ scale, int Cout, int TY, int TX, int Cin, int64_t sn,
+                                                          int64_t sty, int64_t stx, int64_t sc, int b, int64_t bid, int64_t nblk) {
     const int c8 = Cin / 8, ntaps = TY * TX;
     const int64_t n8 = (int64_t)Cout * ntaps * c8;
-    const int b = blockIdx.y;
     const float* sb = scale ? scale + (int64_t)b * Cin : nullptr;
     uint4* out = dst + (int64_t)b * n8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = bid * 256 + threadIdx.x; i < n8; i += nblk * 256) {
         // UNIT (sc == 1): consecutive threads read consecutive 32-byte pieces of one (n, tap) row; otherwise consecutive
         // threads take consecutive n (the contiguous index of a transposed read) of one (tap, 8-channel chunk)
         int n, tap, ci;
@@ -130,6 +129,20 @@ __global__ __launch_bounds__(256) void pack_weights_strided_kernel(uint4* __rest
         out[((int64_t)step * Cout + n) * 4 + (c ^ ((n >> 2) & 3))] =
             make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
     }
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(256) void pack_weights_strided_kernel(uint4* __restrict__ dst, const float* __restrict__ w,
+                                                                   const float* __restrict__ scale, int Cout, int TY, int TX, int Cin,
+                                                                   int64_t sn, int64_t sty, int64_t stx, int64_t sc) {
+    pack_weights_strided_body<UNIT>(dst, w, scale, Cout, TY, TX, Cin, sn, sty, stx, sc, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const ideas_prep_desc* __restrict__ tbl, int n) {
+    int local, nblk;
+    const ideas_prep_desc* d = prep_lookup(tbl, n, local, nblk);
+    if (d->unit) pack_weights_strided_body<true>((uint4*)d->dst, d->w, nullptr, d->a[0], d->a[1], d->a[2], d->a[3], d->s[0], d->s[1], d->s[2], d->s[3], 0, local, nblk);
+    else pack_weights_strided_body<false>((uint4*)d->dst, d->w, nullptr, d->a[0], d->a[1], d->a[2], d->a[3], d->s[0], d->s[1], d->s[2], d->s[3], 0, local, nblk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -695,6 +708,10 @@ extern "C" int ideas_bf16_pack_weights(void* pack, const void* wmat, const float
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, in_scale ? B : 1), dim3(256), 0, (hipStream_t)stream_, (uint4*)pack,
                        (const float4*)wmat, in_scale, Cout, K, Cin);
     return ideas_launch_status();
+}
+
+void ideas_bf16_pack_batched(const ideas_prep_desc* tbl, int n, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(blocks), dim3(256), 0, stream, tbl, n);
 }
 
 extern "C" int ideas_bf16_pack_weights_strided(void* pack, const float* w, const float* in_scale, int B, int Cout, int TY, int TX,

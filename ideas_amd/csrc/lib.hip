@@ -17,3 +17,17 @@ extern "C" const char* ideas_strerror(int code) {
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown ideas_hip error";
 }
+
+extern "C" int ideas_sizeof_prep_desc(void) { return (int)sizeof(ideas_prep_desc); }
+
+extern "C" int ideas_weight_prep_batched(const ideas_prep_desc* table, int n, int op, int total_blocks, void* stream) {
+    if (!table) return IDEAS_E_NULL;
+    if (n <= 0 || total_blocks <= 0) return IDEAS_E_SHAPE;
+    switch (op) {
+        case IDEAS_PREP_B3_SPLIT: ideas_b3_split_batched(table, n, total_blocks, (hipStream_t)stream); break;
+        case IDEAS_PREP_B3_WINO: ideas_b3_wino_split_batched(table, n, total_blocks, (hipStream_t)stream); break;
+        case IDEAS_PREP_BF16_PACK: ideas_bf16_pack_batched(table, n, total_blocks, (hipStream_t)stream); break;
+        default: return IDEAS_E_UNSUPPORTED;
+    }
+    return ideas_launch_status();
+}

@@ -74,7 +74,14 @@ def b3_wino_planes(w: torch.Tensor, transposed: bool) -> torch.Tensor:
         _lib.check(_lib.load().ideas_b3_wino_split_weights(_lib.ptr(pl), _lib.ptr(wm), n, c, sn, sky, skx, sc, base,
                                                             _lib.stream_ptr()), "ideas_b3_wino_split_weights")
         return pl
-    return conv_plan.cached(w, ("b3wino", transposed), make)
+    prep = None
+    wm0 = w.permute(0, 2, 3, 1)
+    if wm0.is_contiguous() and w.shape[1] % 16 == 0:        # read in place: the same call as an entry of the batched refill
+        o, i = w.shape[0], w.shape[1]
+        n, c, sn, sky, skx, sc, base = (i, o, 1, -3 * i, -i, 9 * i, 8 * i) if transposed else (o, i, 9 * i, 3 * i, i, 1, 0)
+        if c % 16 == 0:
+            prep = (_lib.PREP_B3_WINO, 12 * n * 3 * c, (n, c), (sn, sky, skx, sc, base), 0, wm0.data_ptr(), n * 3 * (c // 4))
+    return conv_plan.cached(w, ("b3wino", transposed), make, prep)
 
 
 def launch_wino(y, x, umat, b, cin, h, w, cout, gain, reflect, in_scale=None, out_scale=None, bias=None, resid=None,
@@ -115,7 +122,11 @@ def bf16_pack(L: Launch, in_scale=None) -> torch.Tensor:
         return pk
     if in_scale is not None or L.wsrc is None:
         return make()
-    return conv_plan.cached(L.wsrc, ("bf16",) + L.wkey, make)
+    sn, sty, stx, sc = v.stride()
+    unit = sc == 1 and v.data_ptr() % 16 == 0 and sn % 4 == 0 and sty % 4 == 0 and stx % 4 == 0
+    prep = (_lib.PREP_BF16_PACK, L.Cout * L.TY * L.TX * L.Cin, (L.Cout, L.TY, L.TX, L.Cin), (sn, sty, stx, sc), unit, v.data_ptr(),
+            L.Cout * L.TY * L.TX * (L.Cin // 8)) if L.Cin % 32 == 0 else None
+    return conv_plan.cached(L.wsrc, ("bf16",) + L.wkey, make, prep)
 
 
 def b3_planes(L: Launch) -> torch.Tensor:
@@ -128,7 +139,13 @@ def b3_planes(L: Launch) -> torch.Tensor:
         _lib.check(_lib.load().ideas_b3_split_weights_strided(_lib.ptr(pl), _lib.ptr(v), L.Cout, L.TY, L.TX, L.Cin, sn, sty, stx, sc,
                                                                _lib.stream_ptr()), "ideas_b3_split_weights_strided")
         return pl
-    return conv_plan.cached(L.wsrc, ("b3",) + L.wkey, split) if L.wsrc is not None else split()
+    if L.wsrc is None:
+        return split()
+    sn, sty, stx, sc = v.stride()
+    unit = sc == 1 and v.data_ptr() % 16 == 0 and sn % 4 == 0 and sty % 4 == 0 and stx % 4 == 0
+    prep = (_lib.PREP_B3_SPLIT, 3 * L.Cout * L.TY * L.TX * L.Cin, (L.Cout, L.TY, L.TX, L.Cin), (sn, sty, stx, sc), unit, v.data_ptr(),
+            L.Cout * L.TY * L.TX * (L.Cin // 4)) if L.Cin % 16 == 0 else None
+    return conv_plan.cached(L.wsrc, ("b3",) + L.wkey, split, prep)
 
 
 def _params(L: Launch, gain: float, accumulate: bool = False, act: bool = False, alpha: float = 0.2,
@@ -320,7 +337,7 @@ _GU = {}
 def _wino_gu_scratch(n: int, device) -> torch.Tensor:
     """ZEROED f32 scratch for the Winograd-domain gradient dU, one per (stream, size): the fold kernel re-zeroes it behind its
     read, so it is filled once and never again.  Keyed by stream because the gradient sink runs weight gradients on its own."""
-    key = (torch.cuda.current_stream().cuda_stream, n, str(device))
+    key = (_lib.stream_ptr(), n, str(device))
     buf = _GU.get(key)
     if buf is None:
         buf = _GU[key] = torch.zeros(n, device=device, dtype=torch.float32)

@@ -87,19 +87,102 @@ class Launch:
 # ---------------------------------------------------------------------------------------------------------------
 _CACHE = None
 
+# Batched refill.  Most derived forms are "parameter -> bf16 planes / pack" by one of three kernels; remade one by one they are ~390
+# launches of 5-25 us per iteration (f32; ~290 in bf16), most too small to fill the chip.  A miss that comes with a ``prep``
+# description (op, destination elements, dims, strides, source address) is remembered across iterations; from then on
+# ``cache_begin`` (all of them) and ``cache_clear(params)`` (those derived from the stepped parameters) remake the remembered forms
+# with ONE launch per op (ideas_weight_prep_batched) into persistent buffers, and the first use finds them in the cache.
+# Entries whose parameter died or moved are dropped.  IDEAS_PREFILL=0 keeps the one-by-one path.
+import os as _os
+import weakref as _weakref
+
+PREFILL = _os.environ.get("IDEAS_PREFILL", "1") != "0"
+_RECORDED = {}      # cache key -> (prep, weakref of the base parameter, its data_ptr when recorded)
+_PREP_STATE = {}    # tuple of cache keys -> per-op launch state (device table, blocks, persistent outputs)
+
+
+def _prep_state(keys):
+    import ctypes as C
+    from .. import _lib
+    st = _PREP_STATE.get(keys)
+    if st is not None:
+        return st
+    by_op = {}
+    for k in keys:
+        by_op.setdefault(_RECORDED[k][0][0], []).append(k)
+    st = []
+    for op, ks in sorted(by_op.items()):
+        descs = (_lib.PrepDesc * len(ks))()
+        outs, block0 = [], 0
+        dev = None
+        for i, k in enumerate(ks):
+            (_, numel, a, sv, unit, src, work), ref, _p0 = _RECORDED[k]
+            base = ref()
+            dev = base.device
+            out = torch.empty(numel, device=dev, dtype=torch.bfloat16)
+            nb = int(min(work // 256 + 1, 2048))
+            d = descs[i]
+            d.dst, d.w = out.data_ptr(), src
+            for j in range(5):
+                d.s[j] = sv[j] if j < len(sv) else 0
+            for j in range(4):
+                d.a[j] = a[j] if j < len(a) else 0
+            d.unit, d.block0, d.nblocks = int(unit), block0, nb
+            block0 += nb
+            outs.append((k, out))
+        table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+        st.append((op, table, len(ks), block0, outs))
+    _PREP_STATE[keys] = st
+    return st
+
+
+def _prefill(spans=None) -> None:
+    """Remake the remembered derived forms (of the parameters inside ``spans``, or all) into the cache, one launch per op."""
+    if not PREFILL or _CACHE is None or not _RECORDED:
+        return
+    import bisect
+    from .. import _lib
+    dead = [k for k, (_, ref, p0) in _RECORDED.items() if ref() is None or ref().data_ptr() != p0]
+    if dead:
+        for k in dead:
+            del _RECORDED[k]
+        _PREP_STATE.clear()
+    if spans is None:
+        keys = tuple(sorted(_RECORDED, key=lambda k: (k[0], repr(k[1:]))))
+    else:
+        starts = [m[0] for m in spans]
+        keys = []
+        for k in _RECORDED:
+            i = bisect.bisect_right(starts, k[0]) - 1
+            if i >= 0 and k[0] < spans[i][1]:
+                keys.append(k)
+        keys = tuple(sorted(keys, key=lambda k: (k[0], repr(k[1:]))))
+    if not keys:
+        return
+    lib = _lib.load()
+    for op, table, n, blocks, outs in _prep_state(keys):
+        _lib.check(lib.ideas_weight_prep_batched(table.data_ptr(), n, op, blocks, _lib.stream_ptr()), "ideas_weight_prep_batched")
+        for k, out in outs:
+            _CACHE[k] = out
+
 
 def cache_begin() -> None:
     global _CACHE
     _CACHE = {}
+    _prefill(None)
 
 
-def cache_clear(params=None) -> None:
+def cache_clear(params=None, refill: bool = True) -> None:
     """Drop the derived weights -- all of them, or (``params``: the tensors an optimiser just stepped) only those derived from these
-    parameters: the D step leaves E's / G's packs alone, which the G phase of the same iteration then reuses."""
+    parameters: the D step leaves E's / G's packs alone, which the G phase of the same iteration then reuses.  ``refill``: remake
+    the remembered forms of those parameters right away in one batched launch per op (pointless after the last step of an
+    iteration, whose cache ends anyway)."""
     if _CACHE is None:
         return
     if params is None:
         _CACHE.clear()
+        if refill:
+            _prefill(None)
         return
     spans = sorted((p.data_ptr(), p.data_ptr() + p.numel() * p.element_size()) for p in params)
     merged = []
@@ -114,6 +197,8 @@ def cache_clear(params=None) -> None:
         i = bisect.bisect_right(starts, k[0]) - 1
         if i >= 0 and k[0] < merged[i][1]:
             del _CACHE[k]
+    if refill:
+        _prefill(merged)
 
 
 def cache_end() -> None:
@@ -121,8 +206,10 @@ def cache_end() -> None:
     _CACHE = None
 
 
-def cached(w: torch.Tensor, key, make):
-    """`make()` memoised on (storage address, shape, key) while the cache is on and `w` is (a view of) a Parameter."""
+def cached(w: torch.Tensor, key, make, prep=None):
+    """`make()` memoised on (storage address, shape, key) while the cache is on and `w` is (a view of) a Parameter.
+    ``prep`` = (op, destination bf16 elements, dims a[<=4], strides s[<=5], unit, source address, work items): the same result as
+    one entry of a batched launch (see _prefill); remembered on a miss."""
     if _CACHE is None:
         return make()
     base = w._base if w._base is not None else w
@@ -133,6 +220,9 @@ def cached(w: torch.Tensor, key, make):
     if v is None:
         v = make()
         _CACHE[k] = v
+        if prep is not None and PREFILL and k not in _RECORDED:
+            _RECORDED[k] = (prep, _weakref.ref(base), base.data_ptr())
+            _PREP_STATE.clear()
     return v
 
 

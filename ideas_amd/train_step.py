@@ -120,7 +120,7 @@ def _params_of(trainer, names) -> List[torch.Tensor]:
     return [p for n in names for p in trainer[n].parameters()]
 
 
-def _step(opt, ema: bool = True, only: Optional[Sequence[torch.Tensor]] = None) -> None:
+def _step(opt, ema: bool = True, only: Optional[Sequence[torch.Tensor]] = None, refill: bool = True) -> None:
     """Optimiser step + invalidation of the derived-weight cache (op/conv_plan.py): the fused Adam kernel writes the
     parameters behind autograd's back, so nothing derived from them may outlive it.  ``ema=False``: a FusedAdamEMA step
     that leaves the EMA copies alone (decay 1: ema = 1 * ema + 0 * p) — for iterations that step a group twice."""
@@ -135,7 +135,8 @@ def _step(opt, ema: bool = True, only: Optional[Sequence[torch.Tensor]] = None) 
     finally:
         if not ema and decay is not None:
             opt.ema_decay = decay
-    conv_plan.cache_clear([p for grp in opt.param_groups for p in grp["params"]])
+    # (refill: the derived forms of the stepped parameters are remade at once, batched -- unless nothing of the iteration is left)
+    conv_plan.cache_clear([p for grp in opt.param_groups for p in grp["params"]], refill=refill)
 
 
 def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optional[StepDraws] = None,
@@ -176,8 +177,8 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         optimiser step): the all-reduce runs on RCCL's stream under whatever is issued in between.  Reducers without
         ``start`` (or no reducer) make it the plain blocking sequence at ``finish()``."""
 
-        def __init__(self, tag, params, opt, ema=True):
-            self.tag, self.params, self.opt, self.ema = tag, params, opt, ema
+        def __init__(self, tag, params, opt, ema=True, refill=True):
+            self.tag, self.params, self.opt, self.ema, self.refill = tag, params, opt, ema, refill
             self.pending = reducer.start(tag, params) if (reducer is not None and hasattr(reducer, "start")) else None
 
         def finish(self):
@@ -187,7 +188,7 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
                 reducer(self.tag, self.params)
             if hook is not None:
                 hook(self.tag, self.params)
-            _step(self.opt, ema=self.ema)
+            _step(self.opt, ema=self.ema, refill=self.refill)
 
     # ------------------------------------------------------------------ D phase (train.py:48-102)
     share = bool(getattr(args, "share_forward", True))
@@ -310,11 +311,11 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         T["g_optim"].zero_grad()
         with grad_sink(ex_params):
             torch.autograd.backward(losses["Ex_loss"], inputs=ex_params, retain_graph=True)
-        ex_step = _Deferred("ex", ex_params, T["ex_optim"])      # Ex's exchange runs under the G-side backward
+        ex_step = _Deferred("ex", ex_params, T["ex_optim"], refill=False)      # Ex's exchange runs under the G-side backward
         with grad_sink(g_params):
             torch.autograd.backward(loss_total, inputs=g_params)
         _sync("g", g_params)
-        _step(T["g_optim"], ema=not path_step)     # one EMA accumulate per iteration
+        _step(T["g_optim"], ema=not path_step, refill=path_step)     # one EMA accumulate per iteration
         ex_step.finish()
     else:
         # The reference's literal schedule (train.py:209-216): Loss_total.backward(retain_graph) -> g step ->

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define IDEAS_ABI_VERSION 2   /* 2: the per-sample reductions of the modulated-conv backward accumulate in double (round 3) */
+#define IDEAS_ABI_VERSION 3   /* 2: the per-sample reductions of the modulated-conv backward accumulate in double (round 3);
+                                 3: ideas_demod_bwd overwrites dot_d, ideas_weight_prep_batched added */
 
 enum { IDEAS_NCHW = 0, IDEAS_NHWC = 1 };
 /* `dtype` of the convolution entry points.  Tensors are f32 in HBM for both values.
@@ -194,6 +195,27 @@ int ideas_bf16_pack_weights(void* pack, const void* wmat, const float* in_scale,
 /* ideas_bf16_pack_weights reading the matrix through strides (see ideas_b3_split_weights_strided). */
 int ideas_bf16_pack_weights_strided(void* pack, const float* w, const float* in_scale, int B, int Cout, int TY, int TX, int Cin,
                                     int64_t sn, int64_t sty, int64_t stx, int64_t sc, void* stream);
+/* The three derived-weight forms above for MANY parameters in one launch per form (the forms are remade after every optimiser
+ * step: one batched launch instead of ~100 small ones per form and network group).  `table` = n descriptors IN DEVICE MEMORY
+ * (the caller builds them once: parameter and destination addresses do not change between steps), `op` selects the form, and
+ * block0 / nblocks give each descriptor's share of the `total_blocks` 256-thread blocks (descriptors sorted by block0, first 0,
+ * contiguous).  Per element the kernels run the single-tensor bodies: results are bitwise those of the calls they replace.
+ *   IDEAS_PREP_B3_SPLIT   dst = planes of ideas_b3_split_weights_strided(w, Cout=a[0], TY=a[1], TX=a[2], Cin=a[3], s = sn,sty,stx,sc)
+ *   IDEAS_PREP_B3_WINO    dst = planes of ideas_b3_wino_split_weights(w, N=a[0], C=a[1], s = sn,sky,skx,sc,base)
+ *   IDEAS_PREP_BF16_PACK  dst = pack of ideas_bf16_pack_weights_strided(w, NULL, 1, Cout=a[0], TY=a[1], TX=a[2], Cin=a[3], s = ...) */
+enum { IDEAS_PREP_B3_SPLIT = 0, IDEAS_PREP_B3_WINO = 1, IDEAS_PREP_BF16_PACK = 2 };
+typedef struct ideas_prep_desc {
+    void* dst;
+    const float* w;
+    int64_t s[5];
+    int a[4];
+    int unit;        /* 1: unit channel stride and 16-byte aligned rows (vector reads), as the single-tensor entry points decide */
+    int block0;
+    int nblocks;
+    int pad_;
+} ideas_prep_desc;
+int ideas_sizeof_prep_desc(void);
+int ideas_weight_prep_batched(const ideas_prep_desc* table, int n, int op, int total_blocks, void* stream);
 /* 1 if ideas_conv_direct / ideas_conv_wgrad_direct with IDEAS_BF16 are the intended path for the geometry: the HBM-bound
  * pointwise layers with <= 8 input or output channels (from-RGB, to-RGB and their gradients).  Everything else without a bf16
  * MFMA kernel (a handful of tiny layers) is computed by the caller in f32 on casts. */

@@ -73,7 +73,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ideas_hip.h but not exported"
     assert set(_lib.EXPORTS) == declared
-    assert _lib.load().ideas_abi_version() == 2
+    assert _lib.load().ideas_abi_version() == 3
     assert _lib.load().ideas_strerror(-2) == b"bad or inconsistent dimension"
     assert ctypes.sizeof(_lib.ConvParams) == _lib.load().ideas_sizeof_conv_params() == 28 * 4
 

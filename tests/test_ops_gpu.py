@@ -793,6 +793,62 @@ def test_b3_transposed_phases_one_pass(case, monkeypatch):
     assert rel_err(got["1"], got["0"]) < 2e-6
 
 
+def test_batched_weight_refill_is_bitwise_the_single_launches():
+    """op/conv_plan.py's batched refill (ideas_weight_prep_batched: split-bf16 planes, Winograd planes, bf16 packs of many parameters
+    in one launch per form) against the single-tensor launches it replaces, after an in-place update of the parameters: bitwise."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd import _lib
+    from ideas_amd.op import conv_plan
+    from ideas_amd.op.conv_plan import ConvGeom, plan_dgrad, plan_fwd
+    torch.manual_seed(11)
+    ws = [torch.nn.Parameter(torch.randn(co, ci, k, k, device="cuda").contiguous(memory_format=CL))
+          for co, ci, k in ((64, 32, 3), (130, 64, 3), (48, 96, 1), (256, 128, 3), (32, 32, 3))]
+    ws.append(torch.nn.Parameter(torch.randn(72, 64, 3, 3, device="cuda")))          # NCHW-contiguous parameter
+    g3, g1, gs2 = ConvGeom(3, 3, 1, 1, False), ConvGeom(1, 1, 1, 0, False), ConvGeom(3, 3, 2, 0, False)
+
+    def forms():
+        out = []
+        for w in ws:
+            k = w.shape[2]
+            L = plan_fwd((2, w.shape[1], 17, 17), w, g3 if k == 3 else g1)
+            out.append(CV.b3_planes(L))
+            if w.shape[1] % 32 == 0:
+                out.append(CV.bf16_pack(L))
+            if k == 3:
+                out.append(CV.b3_wino_planes(w, False))
+                if w.shape[0] % 16 == 0:
+                    out.append(CV.b3_wino_planes(w, True))
+                for Ld in plan_dgrad((2, w.shape[0], 8, 8), w, gs2, (17, 17))[0]:
+                    if Ld.Cin % 16:
+                        continue
+                    out.append(CV.b3_planes(Ld))
+                    if Ld.Cin % 32 == 0:
+                        out.append(CV.bf16_pack(Ld))
+        return out
+    conv_plan.cache_begin()
+    try:
+        first = forms()                                   # misses: made one by one and remembered
+        n_rec = len(conv_plan._RECORDED)
+        assert n_rec >= len(first) - 2                    # (the NCHW parameter's Winograd planes need a permuted copy: not batchable)
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5).add_(0.01)
+        conv_plan.cache_clear(ws)                         # -> batched refill of everything remembered for these parameters
+        hits_before = len(conv_plan._CACHE)
+        assert hits_before >= n_rec
+        batched = [t.clone() for t in forms()]            # cache hits (the batched results)
+        assert len(conv_plan._CACHE) <= hits_before + 2
+    finally:
+        conv_plan.cache_end()
+    single = forms()                                      # cache off: the single-tensor launches
+    assert len(single) == len(batched) == len(first)
+    for a, b, c in zip(batched, single, first):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        assert not torch.equal(a.view(torch.int16), c.view(torch.int16))     # (the update did change them)
+    conv_plan._RECORDED.clear()                           # (what this test remembered must not leak into later tests' refills)
+    conv_plan._PREP_STATE.clear()
+
+
 WGRAD3_CASES = [
     # B, Cin, Cout, H, W (of the conv OUTPUT), stride, reflect, scaled
     (2, 64, 64, 16, 16, 1, False, False),      # one strip, two images in one range: the window is re-primed at the image boundary
