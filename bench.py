@@ -99,7 +99,7 @@ def roofline_probe_bf16(device, batch: int, launches: int):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     alg_bytes = 2.0 * batch * 256 * 256 * 128 * 2          # read x + write y, bf16
-    traffic, note = _pmc_traffic("conv_bf16_kernel", "r02_pmc_bf16") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("conv_bf16_kernel", "r03_pmc_bf16") if batch == 32 else (None, None)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": note,
             "kernel": "conv_bf16_kernel<2,2,2,2,true,false> (LDS-DMA implicit GEMM, v_mfma_f32_32x32x16_bf16, one product per MFMA, "
@@ -113,7 +113,8 @@ def roofline_probe(device, batch: int, launches: int):
     """Dominant kernel on its heaviest instance, G.layers.7.conv2: modulated 3x3, 128 -> 128 channels at 256x256
     (19.33 GFLOP per sample), timed with HIP events on the launch stream over `launches` back-to-back
     launches.  `achieved` = ALGORITHMIC f32 FLOPs / time.  Which kernel runs depends on the dispatch:
-      IDEAS_MATH=b3 (default)   conv_b3_wino_kernel<true,false> (IDEAS_B3_WINO=0: conv_b3_kernel<2,2,2,2,true,false>): every f32
+      IDEAS_MATH=b3 (default)   conv_b3_wino2d_kernel<true,false,32> (IDEAS_B3_WINO2D=0: conv_b3_wino_kernel<true,false,2>;
+                                IDEAS_B3_WINO=0: conv_b3_kernel<2,2,2,2,true,false>): every f32
                                 product = six bf16 MFMA products, so the pipe's ceiling for this arithmetic is the dense
                                 bf16 peak / 6 (the Winograd variant issues 2/3 of them; `peak` does not credit that);
       IDEAS_MATH=f32            conv3x3_wino_kernel<true,false> (1-D Winograd on the f32 MFMA: executes 2/3 of the
@@ -143,12 +144,13 @@ def roofline_probe(device, batch: int, launches: int):
     if CV.MATH == _lib.F32_B3:
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         b3w = CV.B3_WINO
-        kname = "conv_b3_wino_kernel" if b3w else "conv_b3_kernel"
-        traffic, traffic_note = _pmc_traffic(kname, "r02_pmc_b3w" if b3w else "r02_pmc_b3") if batch == 32 else (None, None)
+        kname = "conv_b3_wino2d_kernel" if b3w else "conv_b3_kernel"
+        traffic, traffic_note = _pmc_traffic(kname, "r03_pmc_b3w" if b3w else "r03_pmc_b3") if batch == 32 else (None, None)
         executed = achieved * (4.0 if b3w else 6.0)       # bf16 MFMA FLOPs issued per algorithmic f32 FLOP
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": ("conv_b3_wino_kernel<true,false> (1-D Winograd F(2,3): 2/3 of the products; " if b3w else
+                "kernel": ("conv_b3_wino2d_kernel<true,false,32> (1-D Winograd F(2,3): 2/3 of the products; 2 x 32 pair patches whose "
+                           "input rows are staged once for the three ky taps; " if b3w else
                            "conv_b3_kernel<2,2,2,2,true,false> (") +
                           "f32 operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 products per f32 "
                           "product, f32 accumulate)" + where,
@@ -201,13 +203,13 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
         wino = CV.B3_WINO_WGRAD
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         kern = ("conv_b3_wino_wgrad_kernel<2,2,2,2,true,false> + wino_wgrad_fold_kernel (Winograd-domain, 2/3 of the products; " if wino
-                else "conv_b3_wgrad_kernel<2,2,2,2,true,false> (") + "exact 3-way bf16 split of both operands, 6 bf16 MFMA products per f32 product)"
+                else "conv_b3_wgrad3_kernel<1,true,false> (tap-fused 3x3, rolling activation window in LDS; ") + "exact 3-way bf16 split of both operands, 6 bf16 MFMA products per f32 product)"
     else:
         peak, kern = PEAK_F32_MFMA_TFLOPS, "conv3x3_wino_wgrad_kernel / conv_wgrad_kernel (f32 MFMA)"
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and (bf16 or (CV.MATH == _lib.F32_B3 and not CV.B3_WINO_WGRAD)):
-        traffic, note = _pmc_traffic("conv_bf16_wgrad_kernel" if bf16 else "conv_b3_wgrad_kernel", "r02_pmc_bf16wg" if bf16 else "r02_pmc_b3wg")
+        traffic, note = _pmc_traffic("conv_bf16_wgrad_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r03_pmc_bf16wg" if bf16 else "r03_pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, split-K in XCD-banded "
             "order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
@@ -237,7 +239,7 @@ def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
     ms = e0.elapsed_time(e1) / launches
     nbytes = (batch * 128 * 256 * 256 + batch * 128 * 257 * 257) * (2 if bf16 else 4)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r02_pmc_blurbf16" if bf16 else "r02_pmc_blurf32") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r03_pmc_blurbf16" if bf16 else "r03_pmc_blurf32") if batch == 32 else (None, None)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
             "traffic_source": note,
             "kernel": ("blur4_bf16x8_c2<0>" if bf16 else "blur4_f32_c2<0>") + " (4x4 FIR of a downsampling ConvLayer, two output columns per thread) on "
@@ -284,12 +286,16 @@ def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
     if bf16:
         peak, kern = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_kernel (LDS-DMA implicit GEMM)"
     elif CV.MATH == _lib.F32_B3:
-        peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_b3_kernel (exact 3-way bf16 split, 6 bf16 MFMA products per f32 product)"
+        peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, ("conv_b3_tphase_kernel<true> (the four parity phases from one LDS image of the input; exact 3-way bf16 "
+                                                   "split, 6 bf16 MFMA products per f32 product) + the edge strips on conv_b3_multi_kernel")
     else:
         peak, kern = PEAK_F32_MFMA_TFLOPS, "conv_igemm_kernel (f32 MFMA)"
     elem = 2 if bf16 else 4
+    traffic = note = None
+    if batch == 32 and not bf16 and CV.MATH == _lib.F32_B3:
+        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "r03_pmc_b3tp")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None, "kernel": kern + " on G.layers.7.conv1: stride-2 transposed 3x3 modconv 256->128, 128x128 -> 257x257, B=%d "
+            "traffic": traffic, "traffic_source": note, "kernel": kern + " on G.layers.7.conv1: stride-2 transposed 3x3 modconv 256->128, 128x128 -> 257x257, B=%d "
             "(all output-parity phases of the layer)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
             "algorithmic_bytes_per_launch": float(batch * (128 * 128 * 256 + 257 * 257 * 128) * elem)}
 

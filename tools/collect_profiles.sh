@@ -24,18 +24,19 @@ run_one() {   # $1 = precision, $2 = tag, $3 = weight-gradient kernel source, $4
   P=$1; T=$2; WG=$3; shift 3
   timeout 900 python $R/bench.py --precision $P > $OUT/${T}_bench_default.log 2>&1
   tail -1 $OUT/${T}_bench_default.log > $OUT/${T}_bench_default.json
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_roofline -- python $R/bench.py --precision $P --roofline only > $OUT/${T}_roofline.log 2>&1
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_step -- python $R/bench.py --precision $P --steps 3 --warmup 1 --cpu-baseline skip --roofline off > $OUT/${T}_step.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_roofline -- python $R/bench.py --precision $P --roofline only --also-bf16 off > $OUT/${T}_roofline.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_step -- python $R/bench.py --precision $P --steps 3 --warmup 2 --cpu-baseline skip --roofline off --also-bf16 off > $OUT/${T}_step.log 2>&1
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     tag=$(echo $C | cut -d' ' -f1 | tr 'A-Z' 'a-z')
-    timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${T}_pmc_$tag -- python $R/bench.py --precision $P --roofline only --roofline-launches 6 > $OUT/${T}_pmc_$tag.log 2>&1
+    timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${T}_pmc_$tag -- python $R/bench.py --precision $P --roofline only --roofline-launches 6 --also-bf16 off > $OUT/${T}_pmc_$tag.log 2>&1
   done
   sha $OUT/${T}_source.json "$@"
   sha $OUT/${T}_wgrad_source.json $WG b3.hpp common.hpp
   sha $OUT/${T}_blur_source.json upfirdn2d.hip common.hpp
+  sha $OUT/${T}_direct_source.json conv_b3_tphase.hip b3.hpp common.hpp
 }
-if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wgrad.hip conv_b3_wino.hip b3.hpp common.hpp; fi
+if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wgrad3.hip conv_b3_wino.hip b3.hpp common.hpp; fi
 if [ "$WHAT" = "bf16" ] || [ "$WHAT" = "both" ]; then run_one bf16 bf16 conv_bf16.hip conv_bf16.hip common.hpp; fi
 ls $OUT | head -60

@@ -13,9 +13,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, rnd = sys.argv[1], sys.argv[2]
-KERNEL = {"f32": "conv_b3_wino_kernel", "bf16": "conv_bf16_kernel"}
-WGRAD = {"f32": ("conv_b3_wgrad_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
+KERNEL = {"f32": "conv_b3_wino2d_kernel", "bf16": "conv_bf16_kernel"}
+WGRAD = {"f32": ("conv_b3_wgrad3_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
 BLUR = {"f32": ("blur4_f32_c2", "blurf32"), "bf16": ("blur4_bf16x8_c2", "blurbf16")}                 # bench.py's roofline_hbm entry
+DIRECT = {"f32": ("conv_b3_tphase_kernel", "b3tp"), "bf16": (None, None)}                            # bench.py's roofline_direct entry
 NAMES = {"fetch_size": "fetch_size", "write_size": "write_size", "sq_wave_cycles": "sq_wave", "sq_insts_valu": "sq_insts",
          "sq_lds_bank_conflict": "lds_grbm"}
 for tag, kern in KERNEL.items():
@@ -34,8 +35,12 @@ for tag, kern in KERNEL.items():
         rows = list(csv.DictReader(open(f[0])))
         wk, wtag = WGRAD[tag]
         bk, btag = BLUR[tag]
+        dk, dtag = DIRECT[tag]
         for kname, prefix in ((kern, pre), (wk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wtag}")),
-                              (bk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{btag}"))):
+                              (bk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{btag}")),
+                              (dk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{dtag}"))):
+            if kname is None:
+                continue
             keep = [r for r in rows if kname + "<" in r["Kernel_Name"] or kname + "(" in r["Kernel_Name"]]
             if keep:
                 with open(prefix + "_" + short + ".csv", "w", newline="") as fp:
@@ -48,4 +53,6 @@ for tag, kern in KERNEL.items():
         shutil.copy(os.path.join(src, tag + "_blur_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{BLUR[tag][1]}_source.json"))
     if os.path.exists(os.path.join(src, tag + "_wgrad_source.json")):
         shutil.copy(os.path.join(src, tag + "_wgrad_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{WGRAD[tag][1]}_source.json"))
+    if DIRECT[tag][0] and os.path.exists(os.path.join(src, tag + "_direct_source.json")):
+        shutil.copy(os.path.join(src, tag + "_direct_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{DIRECT[tag][1]}_source.json"))
     print(tag, "->", pre + "_*")
