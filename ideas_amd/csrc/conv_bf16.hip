@@ -30,6 +30,7 @@
 //       inside one image and the per-sample scales d[b,o] * s[b,ci] are applied to the accumulator in the epilogue.
 #include "common.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -361,6 +362,236 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restr
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 layers (forward convs and their input gradients: ~60 % of the bf16 step's convolution time): the
+// activation operand as an LDS IMAGE.  conv_bf16_kernel DMAs a 256-pixel A tile per (32-channel chunk, tap) step -- 16 of its
+// 24 DMA pieces per step, every input pixel nine times -- and the issue cost of those pieces (60-185 cycles each next to 8 MFMAs
+// of 32) is what bounds it: 0.27 of the MFMA peak.  Here a block owns a TR x TP patch of output pixels (4 x 64 or 8 x 32 = 256)
+// and DMAs the (TR + 2) x (TP + 2) input pixels of a chunk ONCE; the nine taps read that image at nine pixel offsets (the im2col
+// gather of a tap is just another row / column base of the ds_read).  Per chunk and wave: 9 weight pieces + 4 image pieces
+// instead of 27.  Zero padding = out-of-range DMA source (the DMA writes zeros).
+//   image:   pixel (r, c) at LDS pixel r * LP + c, 64 B (32 channels), 16-byte chunk k at position k ^ ((c >> 2) & 3): the 32
+//            consecutive pixels an MFMA operand covers are conflict-free at every column offset (enumerated against the
+//            ds_read_b128 lane groups of MI355X_MICROARCH.md); LP = TP + 4 keeps c mod 4 = pixel mod 4;
+//   weights: as conv_bf16_kernel (packed [chunk * 9 + tap][Cout][32], three LDS stages, one piece per wave and step);
+//   steps:   the nine taps of a chunk are unrolled: the weight stage (tap % 3), the image piece slots (even taps <= 6) and the
+//            counted vmcnt of every position are compile-time constants; one raw barrier per tap as before;
+//   waves:   8 = 4 pixel quarters x 2 channel halves of a 256 x 128 tile, weights as the MFMA A operand, epilogue of
+//            conv_bf16_kernel (a lane owns one pixel and four consecutive channels per accumulator quad: 8-byte stores).
+// Requires TY = TX = 3, unit stride, |tap step| = 1 with offset = -step (forward: +1 / -1, input gradient: -1 / +1), output =
+// input size, W % 32 == 0, H % (256 / TP) == 0, Cin % 32 == 0, Cout > 64, no mirror padding.
+// ---------------------------------------------------------------------------------------------------------------
+template <int TP, bool PERIMG>
+__global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+                                                               const void* __restrict__ wpack, const float* __restrict__ out_scale,
+                                                               const float* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                               ideas_conv_params p, int tiles_n, unsigned x_bytes, unsigned w_bytes) {
+    constexpr int TR = 256 / TP;
+    constexpr int LP = TP + 4;                       // LDS pixels per image row (TP + 2 in use)
+    constexpr int NPIX = (TR + 2) * LP;
+    constexpr int NPIECE = (NPIX + 15) / 16;         // 16-pixel (1 KiB) DMA pieces of an image
+    static_assert(NPIECE <= 32, "four image slots per wave");
+    constexpr int IMG = NPIECE * 1024;               // bytes of one image buffer
+    constexpr int BST = 128 * ROW;                   // one weight stage (128 output channels x 64 B)
+    constexpr int SMEM = 2 * IMG + 3 * BST;
+    static_assert(SMEM >= 256 * 12, "epilogue row table");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    unsigned char* const sB = smem + 2 * IMG;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+    const int ppr = p.OW / TP, ppi = (p.OH / TR) * ppr;
+    const int img = tile_m / ppi, prem = tile_m - img * ppi;
+    const int y0 = (prem / ppr) * TR, x0 = (prem % ppr) * TP;
+    const int n0 = tile_n * 128;
+    const int K = 9 * p.Cin;
+    const bool flip = p.dy < 0;                      // input gradient: tap ty reads row oy + 1 - ty
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, (int)w_bytes, (int)RSRC);
+    const unsigned w_img = PERIMG ? (unsigned)img * (unsigned)K * (unsigned)p.Cout * 2u : 0u;
+    const unsigned w_end = w_img + (unsigned)K * (unsigned)p.Cout * 2u;
+
+    // ---- image DMA slots of this wave: piece q = wave + 8 j (duplicates past NPIECE rewrite a piece with the same bytes);
+    // lane l fills position l & 3 of LDS pixel 16 q + (l >> 2) = image pixel (r, c), which must hold chunk (l & 3) ^ ((c >> 2) & 3)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);      // (scalar: the DMA destinations stay in SGPRs)
+    unsigned a_src[4], a_msk[4];
+    int a_dst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = (swave + 8 * j) % NPIECE;
+        const int lp = 16 * q + (lane >> 2);
+        const int r = lp / LP, c = lp - r * LP;
+        const int k = (lane & 3) ^ ((c >> 2) & 3);
+        const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+        const bool ok = r < TR + 2 && c < TP + 2 && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        a_src[j] = (unsigned)(((img * p.IH + (ok ? iy : 0)) * p.IW + (ok ? ix : 0)) * p.Cin + k * 8) * 2u;
+        a_msk[j] = ok ? 0u : 0xffffffffu;
+        a_dst[j] = q * 1024;
+    }
+    auto fetchA = [&](int buf, int j, int chunk) {     // image piece slot j of chunk `chunk` (past the last chunk: zeros, never read)
+        const unsigned off = (a_src[j] + (unsigned)chunk * 64u) | a_msk[j] | (chunk * KB < p.Cin ? 0u : 0xffffffffu);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + buf * IMG + a_dst[j]), 16, (int)off, 0, 0, 0);
+    };
+    int kb_next = 0;                                   // next weight step to fetch, (chunk * 9 + tap) order
+    auto fetchB = [&](int st) {
+        unsigned off = w_img + (unsigned)kb_next * (unsigned)p.Cout * 64u + (unsigned)((n0 + wave * 16) * 64 + lane * 16);
+        off = off < w_end ? off : 0xffffffffu;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sB + st * BST + swave * 1024), 16, (int)off, 0, 0, 0);
+        ++kb_next;
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // operand a of this wave: 32 pixels of patch row prow(a), columns pcol(a) + li.  Fragment address for column shift tx and
+    // K-slice s (byte offset inside the image, operand 0, patch row 0): (col pixel) * 64 + ((2 s + lh) ^ ((col >> 2) & 3)) * 16;
+    // operand 1 is 32 columns (same swizzle class) or one image row further: a constant byte offset
+    constexpr int A1_OFF = TP == 64 ? 32 * ROW : LP * ROW;
+    const int row_base = (TP == 64 ? wm : 2 * wm) * LP * ROW;
+    int fx_off[3][2];
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+        const int c = (flip ? 2 - tx : tx) + li;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) fx_off[tx][s2] = row_base + c * ROW + (((2 * s2 + lh) ^ ((c >> 2) & 3)) << 4);
+    }
+    const int rsw = (li >> 2) & 3;
+    const int b_off = (wn * 64 + li) * ROW;
+    const int pos0 = ((0 + lh) ^ rsw) * 16, pos1 = ((2 + lh) ^ rsw) * 16;
+
+    // one tap: wait for this wave's pieces, barrier, issue the fetches of this position, fragments, 8 MFMAs
+    auto tap_step = [&](auto tapc, int chunk) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int TY = TAP / 3, TX = TAP % 3;
+        // in flight behind the weight piece of this step: the weight piece of the next step and the image pieces issued at the
+        // two previous positions (even positions <= 6 carry one)
+        constexpr int P1 = (TAP + 7) % 9, P2 = (TAP + 8) % 9;
+        constexpr int NFLY = 1 + ((P1 % 2 == 0 && P1 <= 6) ? 1 : 0) + ((P2 % 2 == 0 && P2 <= 6) ? 1 : 0);
+        wait_vmcnt<NFLY>();
+        __builtin_amdgcn_s_barrier();
+        fetchB((TAP + 2) % 3);                                             // weight step + 2 into the stage step - 1 used
+        if (TAP % 2 == 0 && TAP <= 6) fetchA((chunk & 1) ^ 1, TAP / 2, chunk + 1);
+        const unsigned char* img_base = smem + (chunk & 1) * IMG + (flip ? 2 - TY : TY) * LP * ROW;
+        const unsigned char* wb = sB + (TAP % 3) * BST + b_off;
+        bf16x8 fx[2][2], fw[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            fx[a][0] = *reinterpret_cast<const bf16x8*>(img_base + a * A1_OFF + fx_off[TX][0]);
+            fx[a][1] = *reinterpret_cast<const bf16x8*>(img_base + a * A1_OFF + fx_off[TX][1]);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            fw[b][0] = *reinterpret_cast<const bf16x8*>(wb + b * 32 * ROW + pos0);
+            fw[b][1] = *reinterpret_cast<const bf16x8*>(wb + b * 32 * ROW + pos1);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][s2], fx[a][s2], acc[a][b], 0, 0, 0);
+    };
+
+    // prologue: the image of chunk 0 (four slots), weight steps 0 and 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fetchA(0, j, 0);
+    fetchB(0);
+    fetchB(1);
+    const int nc = p.Cin / KB;
+    for (int chunk = 0; chunk < nc; ++chunk) {
+        tap_step(std::integral_constant<int, 0>{}, chunk);
+        tap_step(std::integral_constant<int, 1>{}, chunk);
+        tap_step(std::integral_constant<int, 2>{}, chunk);
+        tap_step(std::integral_constant<int, 3>{}, chunk);
+        tap_step(std::integral_constant<int, 4>{}, chunk);
+        tap_step(std::integral_constant<int, 5>{}, chunk);
+        tap_step(std::integral_constant<int, 6>{}, chunk);
+        tap_step(std::integral_constant<int, 7>{}, chunk);
+        tap_step(std::integral_constant<int, 8>{}, chunk);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- epilogue (conv_bf16_kernel's): tile row = (wm, a, li) -> output pixel of the patch ------------------------------------
+    int64_t* row_off = reinterpret_cast<int64_t*>(smem);
+    if (t < 256) {
+        const int w4 = t >> 6, a = (t >> 5) & 1, l = t & 31;
+        const int prow = TP == 64 ? w4 : 2 * w4 + a, pcol = (TP == 64 ? 32 * a : 0) + l;
+        row_off[t] = (((int64_t)img * p.YH + y0 + prow) * p.YW + x0 + pcol) * p.Cout;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int64_t off = row_off[wm * 64 + a * 32 + li];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * 2 + b) * 32 + 8 * g + 4 * lh;
+                if (n >= p.Cout) continue;           // Cout % 4 == 0
+                float v[4];
+                const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 os = out_scale ? *reinterpret_cast<const float4*>(out_scale + (int64_t)img * p.Cout + n)
+                                            : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float bvv[4] = {bv.x, bv.y, bv.z, bv.w}, osv[4] = {os.x, os.y, os.z, os.w};
+                uint2 rr = make_uint2(0u, 0u);
+                if (resid) rr = *reinterpret_cast<const uint2*>(resid + off + n);
+                const float rv[4] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y)};
+                uint2 prev = make_uint2(0u, 0u);
+                if (p.accumulate) prev = *reinterpret_cast<const uint2*>(y + off + n);
+                const float pv[4] = {bf_lo(prev.x), bf_hi(prev.x), bf_lo(prev.y), bf_hi(prev.y)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float u = acc[a][b][4 * g + j] * p.gain * osv[j] + bvv[j];
+                    if (p.act) u = (u > 0.f ? u : u * p.alpha) * p.act_gain;
+                    if (resid) u = (u + rv[j]) * p.resid_gain;
+                    if (p.accumulate) u += pv[j];
+                    v[j] = u;
+                }
+                *reinterpret_cast<uint2*>(y + off + n) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+            }
+        }
+    }
+}
+
+static bool bf16_img_ok(const ideas_conv_params* p) {
+    static const bool on = [] { const char* e = getenv("IDEAS_BF16_IMG"); return !(e && e[0] == '0'); }();
+    if (!on) return false;
+    if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->osy != 1 || p->osx != 1 || p->ooy || p->oox || p->reflect) return false;
+    if (!((p->dy == 1 && p->offy == -1) || (p->dy == -1 && p->offy == 1)) || p->dx != p->dy || p->offx != p->offy) return false;
+    if (p->OH != p->IH || p->OW != p->IW || p->YH != p->OH || p->YW != p->OW) return false;
+    if (p->Cin % 32 || p->Cout <= 64 || p->OW % 32) return false;
+    const int tp = p->OW % 64 == 0 ? 64 : 32;
+    return p->OH % (256 / tp) == 0;
+}
+
+template <int TP>
+int launch_bf16_img(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias, const void* resid,
+                    const ideas_conv_params* p, hipStream_t stream) {
+    const int64_t tm = (int64_t)p->B * (p->OH / (256 / TP)) * (p->OW / TP);
+    const int tn = (p->Cout + 127) / 128;
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
+    const unsigned w_bytes = (unsigned)((int64_t)(per_image ? p->B : 1) * 9 * p->Cin * p->Cout * 2);
+    if (per_image)
+        hipLaunchKernelGGL((conv_bf16_img_kernel<TP, true>), dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack,
+                           out_scale, bias, (const bf16_t*)resid, *p, tn, x_bytes, w_bytes);
+    else
+        hipLaunchKernelGGL((conv_bf16_img_kernel<TP, false>), dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack,
+                           out_scale, bias, (const bf16_t*)resid, *p, tn, x_bytes, w_bytes);
+    return ideas_launch_status();
 }
 
 template <int WM, int WN, int MT, int NT, int NST = 3>
@@ -741,6 +972,9 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     // 1-3 % on 512-channel layers only and loses badly below; a fourth LDS stage and a register-prefetch pipeline (fragments of
     // tile t+1 read under the MFMAs of tile t) both measured 3-5 % SLOWER than three stages + counted vmcnt.
     const int64_t rows = (int64_t)(per_image ? 1 : p->B) * p->OH * p->OW;
+    if (bf16_img_ok(p))                                   // 3x3 / stride 1: the activation operand as an LDS image (IDEAS_BF16_IMG=0: off)
+        return p->OW % 64 == 0 ? launch_bf16_img<64>(y, x, wpack, per_image, out_scale, bias, resid, p, stream)
+                               : launch_bf16_img<32>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
     if (p->Cout >= 256 && rows >= 256) return launch_bf16_cfg<4, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256 x 128, 8 waves
     if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 128
     if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 64

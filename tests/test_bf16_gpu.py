@@ -68,6 +68,10 @@ CONV_CASES = [
     (1, 256, 384, 3, 1, 1, False, 16, 16), (2, 768, 384, 2, 1, 0, False, 2, 2), (4, 512, 512, 3, 1, 1, False, 4, 4),
     (2, 3, 64, 1, 1, 0, False, 24, 24), (2, 128, 3, 1, 1, 0, False, 32, 32), (2, 8, 16, 3, 1, 1, False, 9, 11),
     (2, 512, 8, 1, 1, 0, False, 16, 16), (2, 1, 32, 1, 1, 0, False, 4, 4),
+    # conv_bf16_img_kernel (3x3 / s1, Cout > 64, W % 32 == 0; forward and, Cin > 64, the input gradient): 4 x 64 and 8 x 32 patches,
+    # several patches per image in both directions, two N tiles with a partial one, three chunks
+    (2, 64, 128, 3, 1, 1, False, 8, 64), (1, 128, 200, 3, 1, 1, False, 4, 128), (2, 96, 96, 3, 1, 1, False, 16, 32),
+    (3, 32, 128, 3, 1, 1, False, 8, 96),
 ]
 
 
@@ -113,7 +117,7 @@ def test_conv_transpose_bf16(ops, bf16_mode, case):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, False, 16), (2, 128, 64, True, 16), (3, 32, 96, False, 12), (2, 96, 96, True, 9),
-                                  (2, 128, 128, False, 32)])
+                                  (2, 128, 128, False, 32), (3, 128, 160, False, 64)])     # (32, 64 wide: conv_bf16_img_kernel, per-sample packs)
 def test_modconv_bf16_vs_f64(ops, bf16_mode, case):
     """Modulated conv (same-resolution, and transposed + blur): the block-level weight modulation of csrc/conv_bf16.hip, the
     per-image tiling for sizes that are not a multiple of the tile, and the per-image split of the weight gradient.
