@@ -381,9 +381,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restr
 //   waves:   8 = 4 pixel quarters x 2 channel halves of a 256 x 128 tile, weights as the MFMA A operand, epilogue of
 //            conv_bf16_kernel (a lane owns one pixel and four consecutive channels per accumulator quad: 8-byte stores).
 // Requires TY = TX = 3, unit stride, |tap step| = 1 with offset = -step (forward: +1 / -1, input gradient: -1 / +1), output =
-// input size, W % 32 == 0, H % (256 / TP) == 0, Cin % 32 == 0, Cout > 64, no mirror padding.
+// input size, W % 16 == 0, H % (256 / TP) == 0 (patches 4 x 64, 8 x 32 or 16 x 16), Cin % 32 == 0, Cout > 32 (N tile 128, or 64 for
+// Cout <= 64); mirror padding (forward only) is a different source pixel per image pixel, nothing else.
 // ---------------------------------------------------------------------------------------------------------------
-template <int TP, bool PERIMG>
+template <int TP, int NT, bool PERIMG>
 __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
                                                                const void* __restrict__ wpack, const float* __restrict__ out_scale,
                                                                const float* __restrict__ bias, const bf16_t* __restrict__ resid,
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
     constexpr int NPIECE = (NPIX + 15) / 16;         // 16-pixel (1 KiB) DMA pieces of an image
     static_assert(NPIECE <= 32, "four image slots per wave");
     constexpr int IMG = NPIECE * 1024;               // bytes of one image buffer
-    constexpr int BST = 128 * ROW;                   // one weight stage (128 output channels x 64 B)
+    constexpr int BN = 64 * NT;                      // output channels of the tile (128, or 64 for the narrow layers)
+    constexpr int BST = BN * ROW;                    // one weight stage (BN output channels x 64 B)
     constexpr int SMEM = 2 * IMG + 3 * BST;
     static_assert(SMEM >= 256 * 12, "epilogue row table");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
     const int ppr = p.OW / TP, ppi = (p.OH / TR) * ppr;
     const int img = tile_m / ppi, prem = tile_m - img * ppi;
     const int y0 = (prem / ppr) * TR, x0 = (prem % ppr) * TP;
-    const int n0 = tile_n * 128;
+    const int n0 = tile_n * BN;
     const int K = 9 * p.Cin;
     const bool flip = p.dy < 0;                      // input gradient: tap ty reads row oy + 1 - ty
 
@@ -426,7 +428,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
         const int lp = 16 * q + (lane >> 2);
         const int r = lp / LP, c = lp - r * LP;
         const int k = (lane & 3) ^ ((c >> 2) & 3);
-        const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+        int iy = y0 - 1 + r, ix = x0 - 1 + c;
+        if (p.reflect) { iy = reflect_coord(iy, p.IH); ix = reflect_coord(ix, p.IW); }     // (mirror padding: every patch pixel exists)
         const bool ok = r < TR + 2 && c < TP + 2 && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         a_src[j] = (unsigned)(((img * p.IH + (ok ? iy : 0)) * p.IW + (ok ? ix : 0)) * p.Cin + k * 8) * 2u;
         a_msk[j] = ok ? 0u : 0xffffffffu;
@@ -438,36 +441,36 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
     };
     int kb_next = 0;                                   // next weight step to fetch, (chunk * 9 + tap) order
     auto fetchB = [&](int st) {
-        unsigned off = w_img + (unsigned)kb_next * (unsigned)p.Cout * 64u + (unsigned)((n0 + wave * 16) * 64 + lane * 16);
+        unsigned off = w_img + (unsigned)kb_next * (unsigned)p.Cout * 64u + (unsigned)((n0 + (swave % (4 * NT)) * 16) * 64 + lane * 16);
         off = off < w_end ? off : 0xffffffffu;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sB + st * BST + swave * 1024), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(sB + st * BST + (swave % (4 * NT)) * 1024), 16, (int)off, 0, 0, 0);
         ++kb_next;
     };
 
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[2][2];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     // operand a of this wave: 32 pixels of patch row prow(a), columns pcol(a) + li.  Fragment address for column shift tx and
     // K-slice s (byte offset inside the image, operand 0, patch row 0): (col pixel) * 64 + ((2 s + lh) ^ ((col >> 2) & 3)) * 16;
     // operand 1 is 32 columns (same swizzle class) or one image row further: a constant byte offset
-    constexpr int A1_OFF = TP == 64 ? 32 * ROW : LP * ROW;
-    const int row_base = (TP == 64 ? wm : 2 * wm) * LP * ROW;
+    constexpr int A1_OFF = TP == 64 ? 32 * ROW : TP == 32 ? LP * ROW : 2 * LP * ROW;
+    const int row_base = (TP == 64 ? wm : TP == 32 ? 2 * wm : 4 * wm + (li >> 4)) * LP * ROW;     // (16-wide: an operand = 2 rows x 16)
     int fx_off[3][2];
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx) {
-        const int c = (flip ? 2 - tx : tx) + li;
+        const int c = (flip ? 2 - tx : tx) + (TP == 16 ? (li & 15) : li);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) fx_off[tx][s2] = row_base + c * ROW + (((2 * s2 + lh) ^ ((c >> 2) & 3)) << 4);
     }
     const int rsw = (li >> 2) & 3;
-    const int b_off = (wn * 64 + li) * ROW;
+    const int b_off = (wn * 32 * NT + li) * ROW;
     const int pos0 = ((0 + lh) ^ rsw) * 16, pos1 = ((2 + lh) ^ rsw) * 16;
 
     // one tap: wait for this wave's pieces, barrier, issue the fetches of this position, fragments, 8 MFMAs
@@ -484,14 +487,14 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
         if (TAP % 2 == 0 && TAP <= 6) fetchA((chunk & 1) ^ 1, TAP / 2, chunk + 1);
         const unsigned char* img_base = smem + (chunk & 1) * IMG + (flip ? 2 - TY : TY) * LP * ROW;
         const unsigned char* wb = sB + (TAP % 3) * BST + b_off;
-        bf16x8 fx[2][2], fw[2][2];
+        bf16x8 fx[2][2], fw[NT][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             fx[a][0] = *reinterpret_cast<const bf16x8*>(img_base + a * A1_OFF + fx_off[TX][0]);
             fx[a][1] = *reinterpret_cast<const bf16x8*>(img_base + a * A1_OFF + fx_off[TX][1]);
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NT; ++b) {
             fw[b][0] = *reinterpret_cast<const bf16x8*>(wb + b * 32 * ROW + pos0);
             fw[b][1] = *reinterpret_cast<const bf16x8*>(wb + b * 32 * ROW + pos1);
         }
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < NT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][s2], fx[a][s2], acc[a][b], 0, 0, 0);
     };
 
@@ -528,7 +531,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
     int64_t* row_off = reinterpret_cast<int64_t*>(smem);
     if (t < 256) {
         const int w4 = t >> 6, a = (t >> 5) & 1, l = t & 31;
-        const int prow = TP == 64 ? w4 : 2 * w4 + a, pcol = (TP == 64 ? 32 * a : 0) + l;
+        const int prow = TP == 64 ? w4 : TP == 32 ? 2 * w4 + a : 4 * w4 + 2 * a + (l >> 4);
+        const int pcol = TP == 64 ? 32 * a + l : TP == 32 ? l : (l & 15);
         row_off[t] = (((int64_t)img * p.YH + y0 + prow) * p.YW + x0 + pcol) * p.Cout;
     }
     __syncthreads();
@@ -536,10 +540,10 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
     for (int a = 0; a < 2; ++a) {
         const int64_t off = row_off[wm * 64 + a * 32 + li];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NT; ++b) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + (wn * 2 + b) * 32 + 8 * g + 4 * lh;
+                const int n = n0 + (wn * NT + b) * 32 + 8 * g + 4 * lh;
                 if (n >= p.Cout) continue;           // Cout % 4 == 0
                 float v[4];
                 const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -566,32 +570,41 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
     }
 }
 
-static bool bf16_img_ok(const ideas_conv_params* p) {
+static int bf16_img_tp(const ideas_conv_params* p) {      // patch width of the image kernel for this geometry, 0 = not its geometry
     static const bool on = [] { const char* e = getenv("IDEAS_BF16_IMG"); return !(e && e[0] == '0'); }();
-    if (!on) return false;
-    if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->osy != 1 || p->osx != 1 || p->ooy || p->oox || p->reflect) return false;
-    if (!((p->dy == 1 && p->offy == -1) || (p->dy == -1 && p->offy == 1)) || p->dx != p->dy || p->offx != p->offy) return false;
-    if (p->OH != p->IH || p->OW != p->IW || p->YH != p->OH || p->YW != p->OW) return false;
-    if (p->Cin % 32 || p->Cout <= 64 || p->OW % 32) return false;
-    const int tp = p->OW % 64 == 0 ? 64 : 32;
-    return p->OH % (256 / tp) == 0;
+    if (!on) return 0;
+    if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->osy != 1 || p->osx != 1 || p->ooy || p->oox) return 0;
+    if (!((p->dy == 1 && p->offy == -1) || (p->dy == -1 && p->offy == 1)) || p->dx != p->dy || p->offx != p->offy) return 0;
+    if (p->OH != p->IH || p->OW != p->IW || p->YH != p->OH || p->YW != p->OW) return 0;
+    if (p->reflect && (p->dy != 1 || p->IH < 2 || p->IW < 2)) return 0;
+    if (p->Cin % 32 || p->Cout <= 32 || p->OW % 16) return 0;
+    const int tp = p->OW % 64 == 0 ? 64 : p->OW % 32 == 0 ? 32 : 16;
+    return p->OH % (256 / tp) == 0 ? tp : 0;
 }
 
-template <int TP>
+template <int TP, int NT>
 int launch_bf16_img(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias, const void* resid,
                     const ideas_conv_params* p, hipStream_t stream) {
     const int64_t tm = (int64_t)p->B * (p->OH / (256 / TP)) * (p->OW / TP);
-    const int tn = (p->Cout + 127) / 128;
+    const int tn = (p->Cout + 64 * NT - 1) / (64 * NT);
     if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
     const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
     const unsigned w_bytes = (unsigned)((int64_t)(per_image ? p->B : 1) * 9 * p->Cin * p->Cout * 2);
     if (per_image)
-        hipLaunchKernelGGL((conv_bf16_img_kernel<TP, true>), dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack,
-                           out_scale, bias, (const bf16_t*)resid, *p, tn, x_bytes, w_bytes);
+        hipLaunchKernelGGL((conv_bf16_img_kernel<TP, NT, true>), dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (bf16_t*)y, (const bf16_t*)x,
+                           wpack, out_scale, bias, (const bf16_t*)resid, *p, tn, x_bytes, w_bytes);
     else
-        hipLaunchKernelGGL((conv_bf16_img_kernel<TP, false>), dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (bf16_t*)y, (const bf16_t*)x, wpack,
-                           out_scale, bias, (const bf16_t*)resid, *p, tn, x_bytes, w_bytes);
+        hipLaunchKernelGGL((conv_bf16_img_kernel<TP, NT, false>), dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (bf16_t*)y, (const bf16_t*)x,
+                           wpack, out_scale, bias, (const bf16_t*)resid, *p, tn, x_bytes, w_bytes);
     return ideas_launch_status();
+}
+
+template <int NT>
+int launch_bf16_img_tp(int tp, void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
+                       const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    if (tp == 64) return launch_bf16_img<64, NT>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
+    if (tp == 32) return launch_bf16_img<32, NT>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
+    return launch_bf16_img<16, NT>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
 }
 
 template <int WM, int WN, int MT, int NT, int NST = 3>
@@ -972,9 +985,10 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     // 1-3 % on 512-channel layers only and loses badly below; a fourth LDS stage and a register-prefetch pipeline (fragments of
     // tile t+1 read under the MFMAs of tile t) both measured 3-5 % SLOWER than three stages + counted vmcnt.
     const int64_t rows = (int64_t)(per_image ? 1 : p->B) * p->OH * p->OW;
-    if (bf16_img_ok(p))                                   // 3x3 / stride 1: the activation operand as an LDS image (IDEAS_BF16_IMG=0: off)
-        return p->OW % 64 == 0 ? launch_bf16_img<64>(y, x, wpack, per_image, out_scale, bias, resid, p, stream)
-                               : launch_bf16_img<32>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);
+    if (const int tp = bf16_img_tp(p)) {                  // 3x3 / stride 1: the activation operand as an LDS image (IDEAS_BF16_IMG=0: off)
+        if (p->Cout > 64) return launch_bf16_img_tp<2>(tp, y, x, wpack, per_image, out_scale, bias, resid, p, stream);
+        return launch_bf16_img_tp<1>(tp, y, x, wpack, per_image, out_scale, bias, resid, p, stream);
+    }
     if (p->Cout >= 256 && rows >= 256) return launch_bf16_cfg<4, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 256 x 128, 8 waves
     if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 128
     if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 64

@@ -72,6 +72,8 @@ CONV_CASES = [
     # several patches per image in both directions, two N tiles with a partial one, three chunks
     (2, 64, 128, 3, 1, 1, False, 8, 64), (1, 128, 200, 3, 1, 1, False, 4, 128), (2, 96, 96, 3, 1, 1, False, 16, 32),
     (3, 32, 128, 3, 1, 1, False, 8, 96),
+    # ... mirror padding (forward only), the 64-channel N tile, 16 x 16 patches over a larger image
+    (2, 64, 128, 3, 1, 1, True, 8, 64), (2, 32, 64, 3, 1, 1, True, 16, 32), (2, 64, 64, 3, 1, 1, False, 4, 64), (2, 32, 96, 3, 1, 1, False, 32, 48),
 ]
 
 
