@@ -160,11 +160,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int WM, int WN, int MT, int NT, int NST, bool PERIMG, bool REFLECT>
-__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
-                                                           const void* __restrict__ wpack, const float* __restrict__ out_scale,
-                                                           const float* __restrict__ bias, const bf16_t* __restrict__ resid,
-                                                           ideas_conv_params p, int tiles_n, int tiles_per_img, unsigned x_bytes,
-                                                           unsigned w_bytes) {
+__device__ __forceinline__ void conv_bf16_body(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, const void* __restrict__ wpack,
+                                               const float* __restrict__ out_scale, const float* __restrict__ bias,
+                                               const bf16_t* __restrict__ resid, const ideas_conv_params& p, int tile_m, int tile_n,
+                                               int tiles_per_img, unsigned x_bytes, unsigned w_bytes) {
     constexpr int NW = WM * WN;           // waves per block (4 or 8)
     constexpr int BM = WM * MT * 32;      // pixels of the tile
     constexpr int BN = WN * NT * 32;      // output channels of the tile
@@ -178,8 +177,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restr
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t M = (int64_t)p.B * p.OH * p.OW;
-    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
     const int n0 = tile_n * BN;
     // row r of the tile -> output point.  Plain: consecutive points of the flattened (b, oy, ox) grid.  PERIMG (per-sample
     // weights): tiles are cut per image (tile_m = img * tiles_per_img + j), rows past the image's last point are clamped and
@@ -362,6 +359,73 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restr
             }
         }
     }
+}
+
+template <int WM, int WN, int MT, int NT, int NST, bool PERIMG, bool REFLECT>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+                                                           const void* __restrict__ wpack, const float* __restrict__ out_scale,
+                                                           const float* __restrict__ bias, const bf16_t* __restrict__ resid,
+                                                           ideas_conv_params p, int tiles_n, int tiles_per_img, unsigned x_bytes,
+                                                           unsigned w_bytes) {
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    conv_bf16_body<WM, WN, MT, NT, NST, PERIMG, REFLECT>(y, x, wpack, out_scale, bias, resid, p, swz / tiles_n, swz % tiles_n, tiles_per_img,
+                                                         x_bytes, w_bytes);
+}
+
+// Several launches of the family in ONE grid: the output-parity phases of a stride-2 input gradient / transposed conv (4 / 2 / 2 / 1
+// taps; same x, y and scales, own geometry and weight pack each), launch-major and heaviest first, each launch's tiles in their own
+// XCD-banded order -- as conv_b3_multi_kernel.  The bf16 phases are 50-150 us launches: four grid ramps and tails per layer were a
+// third of their time.
+struct BF16Multi {
+    ideas_conv_params p[4];
+    const void* w[4];
+    unsigned w_bytes[4];
+    int tpi[4];
+    int off[5];
+    int n, tiles_n;
+};
+
+template <int WM, int WN, int MT, int NT, bool PERIMG>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_multi_kernel(bf16_t* __restrict__ y, const bf16_t* __restrict__ x,
+                                                                 const float* __restrict__ out_scale, BF16Multi a, unsigned x_bytes) {
+    const int bid = blockIdx.x;
+    const int which = (bid >= a.off[1] && a.n > 1) + (bid >= a.off[2] && a.n > 2) + (bid >= a.off[3] && a.n > 3);
+    const int swz = xcd_swizzle(bid - a.off[which], a.off[which + 1] - a.off[which]);
+    conv_bf16_body<WM, WN, MT, NT, 3, PERIMG, false>(y, x, a.w[which], out_scale, nullptr, nullptr, a.p[which], swz / a.tiles_n,
+                                                     swz % a.tiles_n, a.tpi[which], x_bytes, a.w_bytes[which]);
+}
+
+template <int WM, int WN, int MT, int NT>
+int launch_bf16_multi_cfg(int n, void* y, const void* x, const void* const* wpack, int per_image, const float* out_scale,
+                          const ideas_conv_params* ps, hipStream_t stream) {
+    constexpr int BM_ = WM * MT * 32, BN_ = WN * NT * 32;
+    BF16Multi a;
+    a.n = n;
+    a.tiles_n = (int)ideas_cdiv(ps[0].Cout, BN_);
+    int64_t blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int k = i < n ? i : 0;
+        a.p[i] = ps[k];
+        a.w[i] = wpack[k];
+        a.w_bytes[i] = (unsigned)((int64_t)(per_image ? ps[k].B : 1) * ps[k].TY * ps[k].TX * ps[k].Cin * ps[k].Cout * 2);
+        a.tpi[i] = (int)ideas_cdiv((int64_t)ps[k].OH * ps[k].OW, BM_);
+        a.off[i] = (int)blocks;
+        if (i < n) {
+            const int64_t tm = per_image ? (int64_t)ps[k].B * a.tpi[i] : ideas_cdiv((int64_t)ps[k].B * ps[k].OH * ps[k].OW, BM_);
+            blocks += tm * a.tiles_n;
+            if (blocks > 0x7fffffffLL) return IDEAS_E_SHAPE;
+        }
+    }
+    a.off[n] = (int)blocks;
+    a.off[4] = (int)blocks;
+    const unsigned x_bytes = (unsigned)((int64_t)ps[0].B * ps[0].IH * ps[0].IW * ps[0].Cin * 2);
+    if (per_image)
+        hipLaunchKernelGGL((conv_bf16_multi_kernel<WM, WN, MT, NT, true>), dim3((unsigned)blocks), dim3(64 * WM * WN), 0, stream, (bf16_t*)y,
+                           (const bf16_t*)x, out_scale, a, x_bytes);
+    else
+        hipLaunchKernelGGL((conv_bf16_multi_kernel<WM, WN, MT, NT, false>), dim3((unsigned)blocks), dim3(64 * WM * WN), 0, stream, (bf16_t*)y,
+                           (const bf16_t*)x, out_scale, a, x_bytes);
+    return ideas_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -993,6 +1057,17 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     if (p->Cout > 64) return launch_bf16_cfg<2, 2, 2, 2>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 128
     if (p->Cout > 32) return launch_bf16_cfg<2, 2, 2, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);   // 128 x 64
     return launch_bf16_cfg<4, 1, 1, 1>(y, x, wpack, per_image, out_scale, bias, resid, p, stream);                     // 128 x 32
+}
+
+// ideas_conv_igemm_multi for dtype IDEAS_BF16 (conv_igemm.hip validates): n <= 4 launches sharing x / y / scales
+int ideas_bf16_fwd_multi(int n, void* y, const void* x, const void* const* wpack, int per_image, const float* out_scale,
+                         const ideas_conv_params* ps, hipStream_t stream) {
+    const ideas_conv_params* p = ps;
+    const int64_t rows = (int64_t)(per_image ? 1 : p->B) * p->OH * p->OW;
+    if (p->Cout >= 256 && rows >= 256) return launch_bf16_multi_cfg<4, 2, 2, 2>(n, y, x, wpack, per_image, out_scale, ps, stream);
+    if (p->Cout > 64) return launch_bf16_multi_cfg<2, 2, 2, 2>(n, y, x, wpack, per_image, out_scale, ps, stream);
+    if (p->Cout > 32) return launch_bf16_multi_cfg<2, 2, 2, 1>(n, y, x, wpack, per_image, out_scale, ps, stream);
+    return launch_bf16_multi_cfg<4, 1, 1, 1>(n, y, x, wpack, per_image, out_scale, ps, stream);
 }
 
 // Tile-shape A/B for tools/bench_igemm.py --cfg (not part of the declared ABI; the production dispatch is ideas_bf16_fwd)

@@ -599,7 +599,7 @@ extern "C" int ideas_conv_igemm(void* y, const void* x, const void* wmat, const 
 
 extern "C" int ideas_conv_igemm_multi(int n, void* y, const void* x, const void* const* wmat, const float* in_scale, const float* out_scale,
                                       const ideas_conv_params* params, int dtype, void* stream_) {
-    if (dtype != IDEAS_F32_B3) return IDEAS_E_UNSUPPORTED;
+    if (dtype != IDEAS_F32_B3 && dtype != IDEAS_BF16) return IDEAS_E_UNSUPPORTED;
     if (!y || !x || !wmat || !params) return IDEAS_E_NULL;
     if (n < 1 || n > 4) return IDEAS_E_SHAPE;
     if (!ideas_aligned16(x) || (in_scale && !ideas_aligned16(in_scale))) return IDEAS_E_ALIGN;
@@ -609,12 +609,15 @@ extern "C" int ideas_conv_igemm_multi(int n, void* y, const void* x, const void*
         if (rc) return rc;
         if (!wmat[i]) return IDEAS_E_NULL;
         if (!ideas_aligned16(wmat[i])) return IDEAS_E_ALIGN;
-        if (!ideas_b3_conv_supported(p) || p->reflect || p->act || p->accumulate) return IDEAS_E_UNSUPPORTED;
+        if (p->reflect || p->act || p->accumulate) return IDEAS_E_UNSUPPORTED;
+        if (dtype == IDEAS_BF16 ? !ideas_bf16_conv_supported(p, in_scale != nullptr) : !ideas_b3_conv_supported(p)) return IDEAS_E_UNSUPPORTED;
         // one tensor pair: same x, same y, same channel counts
         if (p->B != params->B || p->IH != params->IH || p->IW != params->IW || p->Cin != params->Cin || p->YH != params->YH ||
             p->YW != params->YW || p->Cout != params->Cout)
             return IDEAS_E_SHAPE;
     }
+    if (dtype == IDEAS_BF16)      // bf16 activations; wmat[i] = the launches' bf16 packs (per sample when in_scale is given: only its presence matters here)
+        return ideas_bf16_fwd_multi(n, y, x, wmat, in_scale != nullptr, out_scale, params, (hipStream_t)stream_);
     return ideas_b3_fwd_multi(n, y, x, wmat, in_scale, out_scale, params, (hipStream_t)stream_);
 }
 

@@ -196,10 +196,21 @@ def launch_multi(y: torch.Tensor, x: torch.Tensor, launches, gain: float, in_sca
     """The output-parity phases of a stride-2 input gradient / transposed conv as ONE grid (ideas_conv_igemm_multi) where the
     split-bf16 kernel covers all of them; False -> the caller launches them one by one."""
     n = len(launches)
-    if not B3_MULTI or n < 2 or n > 4 or x.dtype != torch.float32 or MATH != _lib.F32_B3:
+    if not B3_MULTI or n < 2 or n > 4:
         return False
     lib = _lib.load()
     ps = (_lib.ConvParams * n)(*[_params(L, gain) for L in launches])
+    if x.dtype == BF:           # bf16 family (csrc/conv_bf16.hip::conv_bf16_multi_kernel): the launches' packs, per sample when modulated
+        if not all(lib.ideas_bf16_conv_supported(C.byref(ps[i]), int(in_scale is not None)) for i in range(n)):
+            return False
+        packs = [bf16_pack(L, in_scale) for L in launches]
+        ws = (C.c_void_p * n)(*[_lib.ptr(pk) for pk in packs])
+        rc = lib.ideas_conv_igemm_multi(n, _lib.ptr(y), _lib.ptr(x), ws, _lib.ptr(in_scale), _lib.ptr(out_scale), ps, _lib.BF16,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "ideas_conv_igemm_multi[bf16]")
+        return True
+    if x.dtype != torch.float32 or MATH != _lib.F32_B3:
+        return False
     if not all(lib.ideas_b3_conv_supported(C.byref(ps[i])) for i in range(n)):
         return False
     planes = [b3_planes(L) for L in launches]

@@ -260,7 +260,10 @@ int ideas_wino_wgrad_fold(float* gw, float* gu, int Cout, int Cin, int64_t so, i
  * input gradient / transposed convolution (stylegan2/model.py:250-261, models.py:32-38: the zero-stuffed taps are never multiplied;
  * 4 / 2 / 2 / 1 taps for a 3x3 kernel).  params[i] and wmat[i] (planes of ideas_b3_split_weights) describe launch i; x, y, the
  * per-sample scales, B / IH / IW / Cin / YH / YW / Cout are shared; no bias / resid / act / accumulate / reflect.  The launches run
- * back to back inside one grid, in the order given (put the one with the most taps first): no grid ramp / tail per launch. */
+ * back to back inside one grid, in the order given (put the one with the most taps first): no grid ramp / tail per launch.
+ * dtype IDEAS_BF16: the same for the bf16 family, wmat[i] = the packs of ideas_bf16_pack_weights_strided (one per sample when
+ * in_scale is given -- only its presence is used, the scale is in the packs).  When the launches are the canonical 3x3 / stride-2
+ * / pad-0 phases and Cout > 64, IDEAS_F32_B3 runs them as ONE pass over a shared LDS image of the input (csrc/conv_b3_tphase.hip). */
 int ideas_conv_igemm_multi(int n, void* y, const void* x, const void* const* wmat, const float* in_scale, const float* out_scale,
                            const ideas_conv_params* params, int dtype, void* stream);
 
