@@ -398,6 +398,9 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
 // output row (TP = 32: 4 instead of 6 rows per 2 output rows), one barrier instead of 1.5.  Ablations on the kernel above
 // (WINO_ABL): without the window loads +17 %, without transform + split +11 %, without the LDS stores +13 %.
 // Needs H % TR == 0 and (W / 2) % TP == 0; everything else (weights layout, epilogue, wave roles) is the kernel above.
+// (Tried for the 64-channel N tile as well -- 8 waves, one accumulator column each: 10-20 % SLOWER than the 4-wave kernel above at
+// three blocks per CU (Dreal.1.conv1's input gradient 236 -> 215 TFLOP/s, E.1.conv1 145 -> 117): with half the MFMAs per staged row
+// the single block per CU is latency-bound.  32 < Cout <= 64 stays on the 4-wave kernel.)
 // ---------------------------------------------------------------------------------------------------------------
 template <bool SCALE, bool REFLECT, int TP>
 __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restrict__ y, const float* __restrict__ x,
