@@ -409,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
                                                                 const float* __restrict__ out_scale,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ resid, ideas_conv_params p,
-                                                                int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+                                                                int tiles_n, unsigned x_bytes, unsigned plane_bytes, int ntiles) {
     constexpr int TR = WP / TP;                 // output rows of the patch
     constexpr int SR = (TR + 2) * TP;           // staged pair-rows per chunk
     constexpr int PL = SR * ROWB;               // bytes per plane
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     const int t = threadIdx.x;
     const int H = p.IH, W = p.IW, W2 = W >> 1;
     const int tpr = W2 / TP, tpi = (H / TR) * tpr;          // patches per row block, per image
-    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
-    const int pb = tile_m / tpi, prem = tile_m - pb * tpi;
-    const int y0 = (prem / tpr) * TR, px0 = (prem % tpr) * TP;
-    const int n0 = tile_n * BN;
+    // PERSISTENT blocks: block b runs tiles b, b + G, b + 2G, ... of the XCD-banded order (G = gridDim.x, a multiple of 8, so all
+    // of a block's tiles lie in its own XCD's band); the first window and weight loads of the next tile are issued BEFORE the
+    // epilogue of the current one, so their latency (and the block launch) no longer sits in front of every tile's K loop -- the
+    // 8-chunk layers at 256x256 spend 40 us per tile, ~3 of them in that prologue.
+    int pb, y0, px0, n0;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)uplanes, 0, (int)(12u * plane_bytes), (int)RSRC_FLAGS);
@@ -435,7 +435,14 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     const int r = t >> 2, kq = t & 3;
     const bool stager = r < SR;
     unsigned coff[4], cmask[4], sbase;           // byte offsets of the four window columns; mask = 0xffffffff in the zero padding
-    {
+    auto set_tile = [&](int d) {
+        const int swz = xcd_swizzle(d, ntiles);
+        const int tile_n = swz % tiles_n, tile_m = swz / tiles_n;
+        pb = tile_m / tpi;
+        const int prem = tile_m - pb * tpi;
+        y0 = (prem / tpr) * TR;
+        px0 = (prem % tpr) * TP;
+        n0 = tile_n * BN;
         const int ir = stager ? r / TP : 0, ptx = r % TP;
         int iy = y0 - 1 + ir;
         bool rok = true;
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
             cmask[j] = (rok && cok) ? 0u : 0xffffffffu;
         }
         sbase = (unsigned)(pb * p.Cin + kq * 4) * 4u;
-    }
+    };
     const int a_lds = r * ROWB + ((kq * 8) ^ (((r >> 3) & 1) << 4));
 
     struct Stage { float4 d[4], s; };
@@ -494,12 +501,6 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     const int wv = wave & 3, wh = wave >> 2;
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     // operand rows of sub-step ky: a*32 + ky*TP + li; the swizzle bit is bit 3 of that row (TP is a multiple of 8)
     int f_off[3];
 #pragma unroll
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
         const int row = ky * TP + li;
         f_off[ky] = (wv * 3) * PL + row * ROWB + ((lh ^ ((row >> 3) & 1)) << 4);
     }
-    const unsigned fb_voff = (unsigned)((n0 + wh * 64 + li) * 32 + lh * 16) + (unsigned)(wv * 3) * plane_bytes;
+    unsigned fb_voff = 0;                                 // (set per tile: depends on the tile's first channel)
     struct BFrag { bf16x8 f[2][3]; };
     int b_step = 0;                                       // (chunk * 3 + ky), consumption order
     auto gloadB = [&](BFrag& fb) {
@@ -571,8 +572,25 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     };
     const int nc = p.Cin / BK;
     BFrag fb0, fb1;
-    gloadA(st0);
-    gloadB(fb0);
+    auto begin_tile = [&](int d) {                         // tile d: addresses, then its first window and weight loads
+        set_tile(d);
+        fb_voff = (unsigned)((n0 + wh * 64 + li) * 32 + lh * 16) + (unsigned)(wv * 3) * plane_bytes;
+        k_ci = 0;
+        b_step = 0;
+        gloadA(st0);
+        gloadB(fb0);
+    };
+    float* exch = reinterpret_cast<float*>(smem);
+    const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;
+    int d = blockIdx.x;
+    begin_tile(d);
+    for (;;) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     lstoreA(0, transform_split(st0));
     gloadA(st1);
     __syncthreads();
@@ -583,10 +601,13 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     }
     if (c < nc) step(c, st0, st1, fb0, fb1);
 
-    // ---- epilogue: as above; pair-row er of the patch = output row y0 + er / TP, pair px0 + er % TP ------------------------
-    float* exch = reinterpret_cast<float*>(smem);
-    const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;
+    // ---- epilogue: as above; pair-row er of the patch = output row y0 + er / TP, pair px0 + er % TP.  The next tile's first
+    // loads go out first (the coordinates of THIS tile are copied before set_tile overwrites them) --------------------------------
+    const int e_pb = pb, e_n0 = n0;
     const int64_t opix = (((int64_t)pb * H + y0 + er / TP) * W + 2 * (px0 + er % TP)) * p.Cout;
+    d += gridDim.x;
+    const bool more = d < ntiles;
+    if (more) begin_tile(d);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -598,7 +619,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int cl = cg * 8 + g * 4;
-            const int n = n0 + eh * 64 + hb * 32 + cl;
+            const int n = e_n0 + eh * 64 + hb * 32 + cl;
             if (n < p.Cout) {
                 const float* ex = exch + (eh * 4 * WP + er) * XROW + cl;
                 const float4 m0v = *reinterpret_cast<const float4*>(ex + 0 * WP * XROW);
@@ -611,7 +632,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
                 for (int e = 0; e < 4; ++e) {
                     if (n + e >= p.Cout) continue;
                     const float o2[2] = {(mm[0][e] + mm[1][e]) + mm[2][e], (mm[1][e] - mm[2][e]) - mm[3][e]};
-                    const float os = out_scale ? out_scale[(int64_t)pb * p.Cout + n + e] : 1.f;
+                    const float os = out_scale ? out_scale[(int64_t)e_pb * p.Cout + n + e] : 1.f;
                     const float bvv = bias ? bias[n + e] : 0.f;
 #pragma unroll
                     for (int px = 0; px < 2; ++px) {
@@ -627,6 +648,8 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
             }
         }
         __syncthreads();
+    }
+    if (!more) break;
     }
 }
 
@@ -673,9 +696,11 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
     const int TPsel = (W2 % 32 == 0) ? 32 : (W2 % 16 == 0) ? 16 : (W2 % 8 == 0) ? 8 : 0;
     if (wide && use2d && TPsel && p->IH % (WP / TPsel) == 0 && p->Cin % 16 == 0) {
         auto go2 = [&](auto sc, auto rf, auto tp) {
+            const int64_t nt = tm * tn;                       // persistent: one block per CU (98 KB of LDS each), a multiple of 8
+            const unsigned grid = (unsigned)(nt < 256 ? nt : 256);
             hipLaunchKernelGGL((conv_b3_wino2d_kernel<decltype(sc)::value, decltype(rf)::value, decltype(tp)::value>),
-                               dim3((unsigned)(tm * tn)), dim3(512), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale,
-                               bias, (const float*)resid, *p, tn, x_bytes, plane_bytes);
+                               dim3(grid), dim3(512), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale,
+                               bias, (const float*)resid, *p, tn, x_bytes, plane_bytes, (int)nt);
         };
         using T = std::true_type;
         using F = std::false_type;
