@@ -288,8 +288,13 @@ static bool tphase_match(int n, const ideas_conv_params* ps, int (&order)[4]) {
 int ideas_b3_fwd_tphase(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
                         const ideas_conv_params* ps, hipStream_t stream, ideas_conv_params* strips, const void** strip_w, int* nstrips) {
     *nstrips = 0;
+    // Default: the modulated launches only (the generator's transposed convs).  The discriminators' stride-2 input gradients are 4 %
+    // faster with this kernel in isolation, but inside the training step they run while the weight gradients occupy the side stream,
+    // and there two 256-register blocks per CU co-schedule worse than the generic kernel's three 150-register ones: same-box step
+    // 451.7 ms without this kernel, 454.8 with it everywhere, 449.0 with it on the modulated launches only.
+    // IDEAS_B3_TPHASE = 0: never, 1: every launch of the geometry.
     const char* e = getenv("IDEAS_B3_TPHASE");
-    if (e && e[0] == '0') return -1;
+    if (e ? (e[0] == '0' || (e[0] != '1' && !in_scale)) : !in_scale) return -1;
     int order[4];
     if (!tphase_match(n, ps, order)) return -1;
     TPhase a;
