@@ -72,7 +72,7 @@ def parse():
 
 
 def roofline_probe_bf16(device, batch: int, launches: int):
-    """bf16 mode: the dominant kernel is conv_bf16_kernel<2,2,2,2,true,false> (csrc/conv_bf16.hip) on the same heaviest instance,
+    """bf16 mode: the dominant kernel is conv_bf16_img_kernel<64,2,true> (csrc/conv_bf16.hip; IDEAS_BF16_IMG=0: conv_bf16_kernel) on the same heaviest instance,
     G.layers.7.conv2.  One bf16 MFMA product per algorithmic product: `peak` is the dense bf16 MFMA peak itself."""
     from ideas_amd.op import conv as CV, conv_plan
     from ideas_amd.op.conv_plan import ConvGeom
@@ -99,11 +99,12 @@ def roofline_probe_bf16(device, batch: int, launches: int):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     alg_bytes = 2.0 * batch * 256 * 256 * 128 * 2          # read x + write y, bf16
-    traffic, note = _pmc_traffic("conv_bf16_kernel", "r03_pmc_bf16") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "r03_pmc_bf16") if batch == 32 else (None, None)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": note,
-            "kernel": "conv_bf16_kernel<2,2,2,2,true,false> (LDS-DMA implicit GEMM, v_mfma_f32_32x32x16_bf16, one product per MFMA, "
-                      "f32 accumulate, per-block weight modulation) on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch,
+            "kernel": "conv_bf16_img_kernel<64,2,true> (the activation operand as an LDS image: one DMA of the 6 x 66 input pixels per 32-channel "
+                      "chunk, nine taps read it at pixel offsets; v_mfma_f32_32x32x16_bf16, one product per MFMA, "
+                      "f32 accumulate, per-sample weight packs) on G.layers.7.conv2: 3x3 modconv 128->128 @256x256, B=%d" % batch,
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_hbm_gbs": round(alg_bytes / (ms * 1e-3) / 1e9, 1),
             "hbm_frac_of_8tbs": round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
@@ -284,7 +285,7 @@ def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
     flops = 2.0 * batch * 128 * 128 * 256 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     if bf16:
-        peak, kern = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_kernel (LDS-DMA implicit GEMM)"
+        peak, kern = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_multi_kernel (LDS-DMA implicit GEMM, the four parity phases in one grid)"
     elif CV.MATH == _lib.F32_B3:
         peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, ("conv_b3_tphase_kernel<true> (the four parity phases from one LDS image of the input; exact 3-way bf16 "
                                                    "split, 6 bf16 MFMA products per f32 product) + the edge strips on conv_b3_multi_kernel")
