@@ -1086,8 +1086,229 @@ extern "C" int ideas_tune_bf16_fwd(int cfg, void* y, const void* x, const void* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride-1 convolutions, tap-fused with a rolling activation window (the bf16 sibling of
+// conv_b3_wgrad3.hip):     gw[o][ty][tx][ci] += gain * sum_{b, oy, ox} G(b, oy, ox, o) * X(b, oy + ty + offy, ox + tx + offx, ci)
+// conv_bf16_wgrad_kernel treats the nine taps as nine column tiles of a GEMM: per 32-pixel step it DMAs a 128-channel piece of G
+// and of X for 32 MFMAs (0.5 DMA pieces per MFMA; every G element fetched 9 Cin / 128 times, every X element 9 Cout / 128 times),
+// and is bound by issuing them (13 vector instructions per MFMA with the transpose-read addressing).  Here one block owns a
+// 64 (o) x 64 (ci) tile for ALL nine taps and walks down a 32-pixel-wide column strip of one image:
+//   * per step (one output row of the strip) the DMA brings one 32-pixel row of G and ONE new row of the X window (34 pixels); the
+//     other two window rows are still in LDS (ring of 5 rows: 3 in use, 2 in flight);
+//   * the nine taps are 18 MFMAs per wave on those operands: tap (ty, tx) reads the pixel-major image ([pixel][64 channels], 128 B
+//     rows, chunk c of row r at c ^ (((r >> 1) & 1) << 2) as in conv_b3_wgrad3.hip: conflict-free transpose reads at any pixel
+//     offset) at window row ty and pixel offset tx through ds_read_b64_tr_b16;
+//   * 3 DMA pieces per wave and step for 18 MFMAs (was 4 for 8), counted vmcnt, one raw barrier per step, two steps of DMA in flight.
+// A block's range of rows lies inside ONE image (so the per-sample scales of a modulated conv multiply the accumulators in the
+// epilogue, and nothing is re-primed mid-range); grid = tiles x strips x (image, part) in XCD-banded split-major order; f32
+// atomics into gw.  Requires TY = TX = 3, unit stride / dilation, OW % 32 == 0, Cin % 64 == 0, Cout % 64 == 0, dense G.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int w3_chunk_off(int r, int c) { return (r * 8 + (c ^ (((r >> 1) & 1) << 2))) * 16; }
+
+template <bool SCALE, bool REFLECT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_wgrad3_kernel(float* __restrict__ gw, const bf16_t* __restrict__ gy,
+                                                                  const bf16_t* __restrict__ x, const float* __restrict__ in_scale,
+                                                                  const float* __restrict__ out_scale, ideas_conv_params p,
+                                                                  int tiles_ci, int tiles, int splits, int strips, int parts,
+                                                                  int rows_per_part, unsigned gy_bytes, unsigned x_bytes) {
+    constexpr int XW = 40;                      // LDS pixels per window row (34 in use; 5 DMA pieces)
+    constexpr int NR = 5;                       // ring of window rows: 3 in use + 2 in flight
+    constexpr int NG = 3;                       // G row buffers: 1 in use + 2 in flight
+    constexpr int XBYTES = NR * XW * 128, GBYTES = NG * 32 * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[XBYTES + GBYTES];
+    unsigned char* const sX = smem;
+    unsigned char* const sG = smem + XBYTES;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    int tile, split;
+    splitk_xcd_map(blockIdx.x, tiles, splits, tile, split);
+    const int o0 = (tile / tiles_ci) * 64, c0 = (tile % tiles_ci) * 64;
+    const int strip = split % strips, rng = split / strips;
+    const int img = rng / parts, part = rng - img * parts;
+    const int ox0 = strip * 32;
+    const int oa = part * rows_per_part;
+    const int ob = oa + rows_per_part < p.OH ? oa + rows_per_part : p.OH;
+    if (oa >= ob) return;
+
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, (int)gy_bytes, (int)RSRC);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC);
+
+    // ---- DMA slots of a wave per step: G piece `swave` (8 pixels), X piece `swave`, X piece 4 (every wave: same bytes) --------------
+    // lane l fills position l & 7 of LDS pixel 8 q + (l >> 3), which must hold channel chunk (l & 7) ^ (((pixel >> 1) & 1) << 2)
+    const int lpx = lane >> 3, lpos = lane & 7;
+    unsigned g_col, x_col[2];
+    bool x_ok[2];
+    {
+        const int px = 8 * swave + lpx;
+        g_col = (unsigned)((ox0 + px) * p.Cout + o0 + 8 * (lpos ^ (((px >> 1) & 1) << 2))) * 2u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int j = 8 * (k == 0 ? swave : 4) + lpx;              // window column 0..39
+            int ix = ox0 + p.offx + j;
+            bool ok = j < 34;
+            if (REFLECT) ix = reflect_coord(ix, p.IW); else ok = ok && ix >= 0 && ix < p.IW;
+            x_ok[k] = ok;
+            x_col[k] = (unsigned)((ok ? ix : 0) * p.Cin + c0 + 8 * (lpos ^ (((j >> 1) & 1) << 2))) * 2u;
+        }
+    }
+    // task n (n = 0, 1, ...): window row wy = oa - 1 + n relative to offy + 1 (input row oa + offy + n); it completes output row
+    // oy = oa + n - 2 when n >= 2.  The last task is n = (ob - oa) + 1.
+    const int ntask = ob - oa + 2;
+    auto dma = [&](int n) {
+        const bool live = n < ntask;
+        int iy = oa + p.offy + n;
+        bool yok = live;
+        if (REFLECT) iy = reflect_coord(iy, p.IH); else yok = yok && iy >= 0 && iy < p.IH;
+        const unsigned xrow = (unsigned)((img * p.IH + (yok ? iy : 0)) * p.IW) * (unsigned)p.Cin * 2u;
+        const bool gl = live && n >= 2;
+        const unsigned grow = (unsigned)((img * p.OH + (gl ? oa + n - 2 : 0)) * p.OW) * (unsigned)p.Cout * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, LDS_PTR(sG + ((n % NG) * 32 + 8 * swave) * 128), 16, (int)(gl ? grow + g_col : 0xffffffffu), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(sX + ((n % NR) * XW + 8 * swave) * 128), 16,
+                                                 (int)((yok && x_ok[0]) ? xrow + x_col[0] : 0xffffffffu), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(sX + ((n % NR) * XW + 32) * 128), 16,
+                                                 (int)((yok && x_ok[1]) ? xrow + x_col[1] : 0xffffffffu), 0, 0, 0);
+    };
+
+    // ---- MFMA side: wave = (o half, ci half); 9 accumulators of 32 (o) x 32 (ci) ----------------------------------------------------
+    const int wo = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int g_q = lane & 15, g_row = g_q >> 2, g_piece = g_q & 3, g_cblk = (lane >> 4) & 1;
+    auto tr_off = [&](int r, int cb) { return w3_chunk_off(r, cb * 2 + (g_piece >> 1)) + (g_piece & 1) * 8; };
+    const unsigned ldsG = (unsigned)(uintptr_t)LDS_PTR(sG), ldsX = (unsigned)(uintptr_t)LDS_PTR(sX);
+    auto tr_ld = [&](unsigned addr) -> s16x4 {
+        s16x4 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
+    };
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    // per-lane byte offsets of the two transpose blocks of K-slice s (pixels 16 s + 8 lh + 0..7) at pixel offset tx, row slot 0
+    int offG[2][2], offX[3][2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            offG[s2][h] = tr_off(16 * s2 + 8 * lh + 4 * h + g_row, wo * 2 + g_cblk);
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) offX[tx][s2][h] = tr_off(16 * s2 + 8 * lh + 4 * h + g_row + tx, wc * 2 + g_cblk);
+        }
+    f32x16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    dma(0);
+    dma(1);
+    for (int n = 0; n < ntask; ++n) {
+        wait_vmcnt<3>();                            // this wave's pieces of task n have landed (task n + 1's three stay in flight)
+        __builtin_amdgcn_s_barrier();               // ... and everybody else's; all waves are done with task n - 1's buffers
+        dma(n + 2);
+        if (n < 2) continue;                        // priming: the window is not complete yet (block-uniform)
+        const unsigned gb = ldsG + (unsigned)((n % NG) * 32 * 128);
+        unsigned xb[3];
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) xb[ty] = ldsX + (unsigned)(((n - 2 + ty) % NR) * XW * 128);
+        // (the (r >> 1) & 1 swizzle of a row slot: XW * slot and 32 * buffer are multiples of 4, so it depends on the pixel only)
+        // The transpose reads are inline asm (see conv_bf16_wgrad_kernel), so the waits are placed by hand: LDS operations return in
+        // order, the reads of tap + 1 are issued before the MFMAs of tap, and lgkmcnt(4) = "everything but the last four reads".
+        s16x4 rg_[2][2], rx_[2][2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rg_[s2][h] = tr_ld(gb + (unsigned)offG[s2][h]);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) rx_[0][s2][h] = tr_ld(xb[0] + (unsigned)offX[0][s2][h]);
+        bf16x8 fa[2];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) {
+                const int ty = (tap + 1) / 3, tx = (tap + 1) - 3 * ty;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) rx_[(tap + 1) & 1][s2][h] = tr_ld(xb[ty] + (unsigned)offX[tx][s2][h]);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap == 0) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const s16x8 v = {rg_[s2][0][0], rg_[s2][0][1], rg_[s2][0][2], rg_[s2][0][3], rg_[s2][1][0], rg_[s2][1][1], rg_[s2][1][2], rg_[s2][1][3]};
+                    fa[s2] = __builtin_bit_cast(bf16x8, v);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const s16x4 a = rx_[tap & 1][s2][0], b = rx_[tap & 1][s2][1];
+                const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2], __builtin_bit_cast(bf16x8, v), acc[tap], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    wait_vmcnt<0>();
+
+    // ---- epilogue: D rows = o (r & 3) + 8 (r >> 2) + 4 lh, column = ci li; gw is OHWI ---------------------------------------------
+    const int ci = c0 + wc * 32 + li;
+    const float sk = SCALE ? in_scale[(int64_t)img * p.Cin + ci] * p.gain : p.gain;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float so = SCALE ? out_scale[(int64_t)img * p.Cout + o] * sk : sk;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) atomicAdd(&gw[((int64_t)o * 9 + tap) * p.Cin + ci], acc[tap][r] * so);
+    }
+}
+
+static bool bf16_wgrad3_ok(const ideas_conv_params* p) {
+    static const bool on = [] { const char* e = getenv("IDEAS_BF16_WGRAD3"); return !(e && e[0] == '0'); }();
+    if (!on) return false;
+    if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->dy != 1 || p->dx != 1) return false;
+    if (p->osy != 1 || p->osx != 1 || p->ooy || p->oox || p->YH != p->OH || p->YW != p->OW) return false;
+    if (p->OW % 32 || p->Cin % 64 || p->Cout % 64 || p->OH < 8) return false;
+    if (p->offx > 0 || p->offx < -2 || p->offy > 0 || p->offy < -2) return false;
+    if (p->reflect && (p->IH < 2 || p->IW < 2)) return false;
+    // (small layers: the generic kernel's fewer, fatter splits win -- E.2.conv1, 64 -> 128 at 128x128, B = 32: 549 vs 459 TFLOP/s)
+    return (int64_t)p->B * p->OH * p->OW * p->Cin * p->Cout >= 6000000000LL;
+}
+
+int launch_bf16_wgrad3(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale, const ideas_conv_params* p,
+                       hipStream_t stream) {
+    const int tiles_ci = p->Cin / 64, tiles = (p->Cout / 64) * tiles_ci;
+    const int strips = p->OW / 32;
+    // parts per image: about four waves of the 512 resident blocks (two per CU) while a part keeps >= 32 rows, at least 8 rows
+    const int64_t base = (int64_t)tiles * strips * p->B;
+    int64_t parts = (4 * 512) / base;
+    if (parts < 1) parts = 1;
+    while (parts > 1 && p->OH / parts < 32) --parts;
+    if (parts > p->OH / 8) parts = p->OH / 8 > 0 ? p->OH / 8 : 1;
+    const int rows = (int)ideas_cdiv(p->OH, parts);
+    parts = ideas_cdiv(p->OH, rows);
+    const int64_t splits = (int64_t)strips * p->B * parts;
+    if ((int64_t)tiles * splits > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    const unsigned gy_bytes = (unsigned)((int64_t)p->B * p->YH * p->YW * p->Cout * 2);
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 2);
+    auto go = [&](auto s_, auto rf) {
+        hipLaunchKernelGGL((conv_bf16_wgrad3_kernel<decltype(s_)::value, decltype(rf)::value>), dim3(splitk_grid(tiles, splits)), dim3(256), 0,
+                           stream, gw, (const bf16_t*)gy, (const bf16_t*)x, in_scale, out_scale, *p, tiles_ci, tiles, (int)splits, strips,
+                           (int)parts, rows, gy_bytes, x_bytes);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool sc = in_scale && out_scale;
+    if (sc) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
+    else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
 int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                      const ideas_conv_params* p, hipStream_t stream) {
+    if (bf16_wgrad3_ok(p)) return launch_bf16_wgrad3(gw, gy, x, in_scale, out_scale, p, stream);    // 3x3 / s1: tap-fused, rolling window
     // (an 8-wave 256 x 128 tile, the winner of the forward family, measured 22 % SLOWER here: half the blocks for the split-K)
     if (p->Cout > 64) return launch_bf16_wgrad_cfg<2, 2, 2, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 128 (o) x 128 (k)
     if (p->Cout > 32) return launch_bf16_wgrad_cfg<2, 2, 1, 2>(gw, gy, x, in_scale, out_scale, p, stream);   // 64 x 128

@@ -74,6 +74,9 @@ CONV_CASES = [
     (3, 32, 128, 3, 1, 1, False, 8, 96),
     # ... mirror padding (forward only), the 64-channel N tile, 16 x 16 patches over a larger image
     (2, 64, 128, 3, 1, 1, True, 8, 64), (2, 32, 64, 3, 1, 1, True, 16, 32), (2, 64, 64, 3, 1, 1, False, 4, 64), (2, 32, 96, 3, 1, 1, False, 32, 48),
+    # conv_bf16_wgrad3_kernel (tap-fused weight gradient: Cin, Cout % 64 == 0, W % 32 == 0): three strips, several parts per image,
+    # a 2 x 2 grid of channel tiles (the cases (2, 64, 128, .., 8, 64) above -- plain and mirror-padded -- take it as well)
+    (3, 64, 64, 3, 1, 1, False, 40, 96), (2, 128, 128, 3, 1, 1, False, 16, 32),
 ]
 
 
