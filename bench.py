@@ -199,7 +199,8 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     if bf16:
-        peak, kern = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_wgrad_kernel<2,2,2,2,true,false> (LDS-DMA tiles, ds_read_b64_tr_b16 transpose reads, one bf16 product per MFMA)"
+        peak, kern = PEAK_BF16_MFMA_TFLOPS, ("conv_bf16_wgrad3_kernel<true,false> (tap-fused 3x3: one DMA'd G row + one new X window row per step, nine taps on "
+                                             "ds_read_b64_tr_b16 transpose reads at pixel offsets, one bf16 product per MFMA)")
     elif CV.MATH == _lib.F32_B3:
         wino = CV.B3_WINO_WGRAD
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
@@ -210,10 +211,10 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and (bf16 or (CV.MATH == _lib.F32_B3 and not CV.B3_WINO_WGRAD)):
-        traffic, note = _pmc_traffic("conv_bf16_wgrad_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r03_pmc_bf16wg" if bf16 else "r03_pmc_b3wg")
+        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r03_pmc_bf16wg" if bf16 else "r03_pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, split-K in XCD-banded "
-            "order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
+            "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, column strips x row ranges in "
+            "XCD-banded order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
             "algorithmic_bytes_per_launch": 2.0 * batch * 256 * 256 * 128 * elem}
 
 

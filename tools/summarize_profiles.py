@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, rnd = sys.argv[1], sys.argv[2]
 KERNEL = {"f32": "conv_b3_wino2d_kernel", "bf16": "conv_bf16_img_kernel"}
-WGRAD = {"f32": ("conv_b3_wgrad3_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
+WGRAD = {"f32": ("conv_b3_wgrad3_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad3_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
 BLUR = {"f32": ("blur4_f32_c2", "blurf32"), "bf16": ("blur4_bf16x8_c2", "blurbf16")}                 # bench.py's roofline_hbm entry
 DIRECT = {"f32": ("conv_b3_tphase_kernel", "b3tp"), "bf16": (None, None)}                            # bench.py's roofline_direct entry
 NAMES = {"fetch_size": "fetch_size", "write_size": "write_size", "sq_wave_cycles": "sq_wave", "sq_insts_valu": "sq_insts",
