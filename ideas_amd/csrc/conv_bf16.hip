@@ -635,8 +635,8 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
 }
 
 static int bf16_img_tp(const ideas_conv_params* p) {      // patch width of the image kernel for this geometry, 0 = not its geometry
-    static const bool on = [] { const char* e = getenv("IDEAS_BF16_IMG"); return !(e && e[0] == '0'); }();
-    if (!on) return 0;
+    const char* e = getenv("IDEAS_BF16_IMG");             // (read per call: the tests toggle it in-process)
+    if (e && e[0] == '0') return 0;
     if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->osy != 1 || p->osx != 1 || p->ooy || p->oox) return 0;
     if (!((p->dy == 1 && p->offy == -1) || (p->dy == -1 && p->offy == 1)) || p->dx != p->dy || p->offx != p->offy) return 0;
     if (p->OH != p->IH || p->OW != p->IW || p->YH != p->OH || p->YW != p->OW) return 0;
@@ -1266,8 +1266,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad3_kernel(float* __restr
 }
 
 static bool bf16_wgrad3_ok(const ideas_conv_params* p) {
-    static const bool on = [] { const char* e = getenv("IDEAS_BF16_WGRAD3"); return !(e && e[0] == '0'); }();
-    if (!on) return false;
+    const char* e = getenv("IDEAS_BF16_WGRAD3");          // (read per call: the tests toggle it in-process)
+    if (e && e[0] == '0') return false;
     if (p->TY != 3 || p->TX != 3 || p->sy != 1 || p->sx != 1 || p->dy != 1 || p->dx != 1) return false;
     if (p->osy != 1 || p->osx != 1 || p->ooy || p->oox || p->YH != p->OH || p->YW != p->OW) return false;
     if (p->OW % 32 || p->Cin % 64 || p->Cout % 64 || p->OH < 8) return false;

@@ -103,6 +103,38 @@ def test_conv_bf16_vs_f64_on_rounded_operands(ops, bf16_mode, case):
     assert rel_err(gwd, gw) < 1e-3, ("gw", case, rel_err(gwd, gw))
 
 
+def test_bf16_image_and_tap_fused_kernels_full_size(monkeypatch):
+    """BASELINE-size check of the round-3 bf16 kernels on G.layers.7.conv2's shape (modulated 128 -> 128 at 256x256, B = 4): the LDS
+    image kernel (forward, input gradient) and the tap-fused weight gradient against the generic kernels they replace on the same
+    operands (same bf16 products, f32 accumulation in another order: a few results land on the other side of a bf16 rounding), and
+    the adjoint identity <gy, conv(x)> == <dgrad(gy), x> between the two image-kernel launches."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    torch.manual_seed(3)
+    B, C, R = 4, 128, 256
+    g = ConvGeom(3, 3, 1, 1, False)
+    x = torch.randn(B, C, R, R, device="cuda").to(BF).contiguous(memory_format=CL)
+    gy = torch.randn(B, C, R, R, device="cuda").to(BF).contiguous(memory_format=CL)
+    w = torch.randn(C, C, 3, 3, device="cuda").contiguous(memory_format=CL)
+    s = torch.rand(B, C, device="cuda") + 0.5
+    d = torch.rand(B, C, device="cuda") + 0.5
+    gain = 1 / math.sqrt(C * 9)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_BF16_IMG", flag)
+        monkeypatch.setenv("IDEAS_BF16_WGRAD3", flag)
+        out[flag] = (CV.conv_fwd_raw(x, w, g, gain, s, d), CV.conv_dgrad_raw(gy, w, g, (R, R), gain, d, s),
+                     CV.conv_wgrad_raw(gy, x, g, tuple(w.shape), gain, s, d))
+    for a, b, what in zip(out["1"], out["0"], ("y", "gx", "gw")):
+        a, b = a.float(), b.float()
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= (2.0 ** -7 if what != "gw" else 1e-4) * scale, what     # at most one bf16 ulp at full scale
+        assert float((a - b).abs().mean()) <= (2e-4 if what != "gw" else 1e-6) * scale, what           # and almost everywhere identical
+    y, gx = out["1"][0].double(), out["1"][1].double()
+    lhs, rhs = float((gy.double() * y).sum()), float((gx * x.double()).sum())
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), float((gy.double() * y).abs().sum()) * 1e-3)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 32, 1, 2, 16, 16), (2, 32, 64, 3, 2, 9, 9), (2, 128, 128, 3, 2, 16, 16)])
 def test_conv_transpose_bf16(ops, bf16_mode, case):
     B, ci, co, k, s, H, W = case

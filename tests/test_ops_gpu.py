@@ -849,6 +849,36 @@ def test_batched_weight_refill_is_bitwise_the_single_launches():
     conv_plan._PREP_STATE.clear()
 
 
+def test_b3_transposed_phases_full_size(monkeypatch):
+    """BASELINE-size check of conv_b3_tphase_kernel on G.layers.7.conv1's shape (modulated transposed 3x3 / stride 2, 256 -> 128,
+    128x128 -> 257x257, B = 4): equal to the four-GEMM grid to f32 round-off, linear in the input, and adjoint to the stride-2
+    convolution that is its input gradient (<gy, convT(x)> == <conv_s2(gy), x>)."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom, convT_out_size
+    torch.manual_seed(4)
+    B, ci, co, H = 4, 256, 128, 128
+    g = ConvGeom(3, 3, 2, 0, False)
+    oh, ow = convT_out_size(H, H, g)
+    x1 = torch.randn(B, ci, H, H, device="cuda").contiguous(memory_format=CL)
+    x2 = torch.randn(B, ci, H, H, device="cuda").contiguous(memory_format=CL)
+    wt = torch.randn(ci, co, 3, 3, device="cuda").contiguous(memory_format=CL)
+    s = torch.rand(B, ci, device="cuda") + 0.5
+    d = torch.rand(B, co, device="cuda") + 0.5
+    gain = 1 / math.sqrt(ci * 9)
+    monkeypatch.setenv("IDEAS_B3_TPHASE", "1")
+    y1 = CV.conv_dgrad_raw(x1, wt, g, (oh, ow), gain, s, d)
+    y2 = CV.conv_dgrad_raw(x2, wt, g, (oh, ow), gain, s, d)
+    y12 = CV.conv_dgrad_raw(x1 + 2 * x2, wt, g, (oh, ow), gain, s, d)
+    assert rel_err(y12, y1.double() + 2 * y2.double()) < 2e-6
+    monkeypatch.setenv("IDEAS_B3_TPHASE", "0")
+    y1m = CV.conv_dgrad_raw(x1, wt, g, (oh, ow), gain, s, d)
+    assert rel_err(y1, y1m) < 2e-6
+    gy = torch.randn(B, co, oh, ow, device="cuda").contiguous(memory_format=CL)
+    gx = CV.conv_fwd_raw(gy, wt, g, gain, d, s)                     # the transposed conv's input gradient: a stride-2 conv of gy
+    lhs, rhs = float((gy.double() * y1.double()).sum()), float((gx.double() * x1.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float((gy.double() * y1.double()).abs().sum())
+
+
 WGRAD3_CASES = [
     # B, Cin, Cout, H, W (of the conv OUTPUT), stride, reflect, scaled
     (2, 64, 64, 16, 16, 1, False, False),      # one strip, two images in one range: the window is re-primed at the image boundary
