@@ -14,8 +14,8 @@
 // pixel shifts (0,0) (0,-1) (-1,0) (-1,-1): a shifted window is just another row address.  108 MFMAs per wave and chunk on one
 // staging pass (340 pixel-quads for 256 threads), one barrier per chunk.
 //   waves: 4 = the 32-channel quarters of a 128-channel N tile; each holds 4 phases x 2 operands (2 x 16 positions each) = 8
-//          accumulators (128 registers); two blocks per CU, so one block's epilogue (it stores 4x the pixels it read) runs under
-//          the other's K loop (a first version with 8-wave blocks, one per CU, paid it in full: +5 % instead of +20 %);
+//          accumulators (128 registers); two blocks per CU (a first version with 8-wave blocks, one per CU, gained 5 % instead
+//          of 20 %).  The epilogue -- a block stores 4x the pixels it read -- is still not overlapped: see the measurements in the kernel;
 //   B:     the per-phase weight planes of ideas_b3_split_weights_strided ([3][chunk * taps + tap][Cout][16] = the MFMA operand
 //          layout) are fetched straight from global memory one tap group ahead, as conv_b3_wino.hip does;
 //   LDS:   two buffers of 3 planes x 5 rows x 32 pixels x 32 B (30 KB; 17 pixels of a row in use); 16-byte halves of a pixel
