@@ -156,7 +156,7 @@ class ModulatedConv2d(nn.Module):
 
     def forward(self, input, style, act: Optional[FusedLeakyReLU] = None, post_gain: float = 1.0,
                 resid: Optional[torch.Tensor] = None):
-        s = self.modulation(style)
+        s = self._styles(style)
         fir = self.blur.kernel if self.upsample else None
         if act is None:
             return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
@@ -164,6 +164,21 @@ class ModulatedConv2d(nn.Module):
         return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=self.upsample, fir=fir,
                                 eps=self.eps, act_bias=act.bias, negative_slope=act.negative_slope,
                                 act_scale=act.scale * post_gain, resid=resid)
+
+    def _styles(self, style):
+        """s = modulation(style), memoised per (modulation weights, texture-code tensor) for the duration of a training iteration:
+        G is applied to the same texture code two or three times (train.py:58, :68, :145-160), so the styles, the demodulation
+        factors and (bf16) the per-sample weight packs of those applications are the same tensors.  Under no_grad the values of an
+        existing grad-mode entry are reused (detached); two grad-mode applications share ONE modulation node, whose gradient is
+        then the sum of both (what autograd computes for a tensor used twice)."""
+        from .op import conv_plan
+        w = self.modulation.weight
+        if torch.is_grad_enabled():
+            return conv_plan.cached_on(w, ("style", 1), style, lambda: self.modulation(style))
+        hit = conv_plan.peek_on(w, ("style", 1), style)
+        if hit is not None:
+            return hit.detach()
+        return conv_plan.cached_on(w, ("style", 0), style, lambda: self.modulation(style))
 
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "

@@ -120,8 +120,10 @@ def bf16_pack(L: Launch, in_scale=None) -> torch.Tensor:
                                                                 L.Cin, sn, sty, stx, sc, _lib.stream_ptr()),
                    "ideas_bf16_pack_weights_strided")
         return pk
-    if in_scale is not None or L.wsrc is None:
+    if L.wsrc is None:
         return make()
+    if in_scale is not None:           # per-sample packs: the same (weights, styles) pair comes back within an iteration (conv_plan.cached_on)
+        return conv_plan.cached_on(L.wsrc, ("bf16s",) + L.wkey, in_scale, make)
     sn, sty, stx, sc = v.stride()
     unit = sc == 1 and v.data_ptr() % 16 == 0 and sn % 4 == 0 and sty % 4 == 0 and stx % 4 == 0
     prep = (_lib.PREP_BF16_PACK, L.Cout * L.TY * L.TX * L.Cin, (L.Cout, L.TY, L.TX, L.Cin), (sn, sty, stx, sc), unit, v.data_ptr(),

@@ -97,6 +97,7 @@ import os as _os
 import weakref as _weakref
 
 PREFILL = _os.environ.get("IDEAS_PREFILL", "1") != "0"
+STYLE_CACHE = _os.environ.get("IDEAS_STYLE_CACHE", "1") != "0"
 _RECORDED = {}      # cache key -> (prep, weakref of the base parameter, its data_ptr when recorded)
 _PREP_STATE = {}    # tuple of cache keys -> per-op launch state (device table, blocks, persistent outputs)
 
@@ -224,6 +225,33 @@ def cached(w: torch.Tensor, key, make, prep=None):
             _RECORDED[k] = (prep, _weakref.ref(base), base.data_ptr())
             _PREP_STATE.clear()
     return v
+
+
+def cached_on(w: torch.Tensor, key, t: torch.Tensor, make):
+    """`make()` memoised on a parameter (as ``cached``) AND on the identity of a second tensor `t` (address + version counter) --
+    the per-sample styles of a modulated conv: G is applied to the same texture code two or three times per iteration (train.py:58,
+    :68, :145-160), and everything derived from (weights, styles) -- the styles themselves, the demodulation factors, the bf16
+    per-sample weight packs -- is then the same.  The entry keeps `t` alive, so its address cannot be reused by another tensor
+    while the entry exists.  IDEAS_STYLE_CACHE=0 switches it off (A/B)."""
+    if _CACHE is None or not STYLE_CACHE:
+        return make()
+    base = w._base if w._base is not None else w
+    if not isinstance(base, torch.nn.Parameter):
+        return make()
+    k = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), key, t.data_ptr(), t._version, tuple(t.shape))
+    v = _CACHE.get(k)
+    if v is None:
+        v = (t, make())
+        _CACHE[k] = v
+    return v[1]
+
+
+def peek_on(w: torch.Tensor, key, t: torch.Tensor):
+    """The memoised value of ``cached_on(w, key, t, ...)`` if there is one, else None."""
+    if _CACHE is None or not STYLE_CACHE:
+        return None
+    v = _CACHE.get((w.data_ptr(), tuple(w.shape), tuple(w.stride()), key, t.data_ptr(), t._version, tuple(t.shape)))
+    return None if v is None else v[1]
 
 
 def plan_fwd(x_shape, w: torch.Tensor, g: ConvGeom) -> Launch:

@@ -74,6 +74,17 @@ def weight_sqsum_f64(w: torch.Tensor, scale: float) -> torch.Tensor:
 def demod_raw(s: torch.Tensor, wsq: torch.Tensor, eps: float) -> torch.Tensor:
     """d[b,o] = rsqrt((s*s) @ wsq^T + eps) on the shuffle-reduction kernel (no autograd: the modulated-conv Functions own the
     derivative, _style_grads / _demod_wgrad)."""
+    return _demod_raw(s.detach(), wsq, eps)
+
+
+def demod_of(w: torch.Tensor, s: torch.Tensor, gain: float, eps: float) -> torch.Tensor:
+    """demod_raw(s, weight_sqsum(w, gain), eps), memoised on (weight, style tensor) while the derived-weight cache is on: the same
+    styles reach a layer two or three times per iteration, and the bf16 packs of the input gradients are keyed on this tensor."""
+    sd = s.detach()
+    return conv_plan.cached_on(w, ("demod", float(gain), float(eps)), sd, lambda: _demod_raw(sd, weight_sqsum(w, gain), eps))
+
+
+def _demod_raw(s: torch.Tensor, wsq: torch.Tensor, eps: float) -> torch.Tensor:
     b, cin = s.shape
     cout = wsq.shape[0]
     d = torch.empty((b, cout), device=s.device, dtype=torch.float32)
@@ -120,7 +131,7 @@ class _ModConv(Function):
     def forward(ctx, x, w, s, up: bool, gain: float, demod: bool, eps: float):
         x = _nhwc(x)
         s = s.contiguous()
-        d = demod_raw(s, weight_sqsum(w, gain), eps) if demod else None
+        d = demod_of(w, s, gain, eps) if demod else None
         k = w.shape[2]
         if up:
             g = ConvGeom(k, k, 2, 0, False)
@@ -197,7 +208,7 @@ class _ModConvAct(Function):
         x = _nhwc(x)
         bias_param = b
         s, b = s.contiguous(), b.contiguous()
-        d = demod_raw(s, weight_sqsum(w, gain), eps)
+        d = demod_of(w, s, gain, eps)
         k = w.shape[2]
         g = ConvGeom(k, k, 1, k // 2, False)
         y = conv_fwd_raw(x, w, g, gain, lin=s, lout=d, bias=b, act=True, act_gain=act_gain, alpha=slope)
