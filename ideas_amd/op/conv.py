@@ -366,6 +366,46 @@ def _wino_fold(gu, out, co: int, ci: int, w_shape, device, clear: bool = True):
     return tgt
 
 
+# Weight gradients of the layers with <= 4x4 output pixels per sample and many samples (the co-occurrence discriminator's last
+# blocks: 1024 patches of 2x2 .. 4x4): as an implicit GEMM over pixels most of a 32-pixel K-step is another sample's padding, and the
+# kernels ran at 50-140 TFLOP/s (7 ms of the bf16 iteration, on f32 kernels behind casts).  Here the im2col matrix is tiny (a few tens
+# of MB), so it is materialised (one cat of the KH*KW shifted views of the padded NHWC tensor) and the gradient is ONE library GEMM
+# [Cout, P] x [P, KH*KW*Cin] (hipBLASLt, f32 accumulation and output) -- the OHWI matrix exactly.  Same box, bf16 iteration:
+# 172.4 -> 169.7 ms.  With f32 activations the library's f32 GEMM is no faster than the b3 kernels (449.4 -> 451.5 ms), so the
+# default (1) takes this path for bf16 activations only; IDEAS_TINY_WGRAD_GEMM=2: f32 too (the parity tests run it), 0: off.
+TINY_WGRAD_GEMM = int(_os.environ.get("IDEAS_TINY_WGRAD_GEMM", "1"))
+PRESCALE_MOD_PIX = int(_os.environ.get("IDEAS_PRESCALE_MOD_PIX", "256"))
+TINY_MAX_PIX = int(_os.environ.get("IDEAS_TINY_MAX_PIX", "16"))
+TINY_MAX_PIX_MOD = int(_os.environ.get("IDEAS_TINY_MAX_PIX_MOD", "16"))
+
+
+def _tiny_spatial_wgrad(gy, x, g: ConvGeom, w_shape, gain: float, out, lin=None, lout=None):
+    b, co, oh, ow = gy.shape
+    ci, kh, kw, st = x.shape[1], w_shape[2], w_shape[3], g.stride
+    xn = x.permute(0, 2, 3, 1)                                    # NHWC view of the channels_last tensor
+    gn = gy.permute(0, 2, 3, 1)
+    if lin is not None:                                           # per-sample scales: applied in f32, rounded once
+        xn = (xn * lin[:, None, None, :].float()).to(x.dtype)
+        gn = (gn * lout[:, None, None, :].float()).to(gy.dtype)
+    if g.pad:
+        xn = torch.nn.functional.pad(xn, (0, 0, g.pad, g.pad, g.pad, g.pad))
+    cols = torch.cat([xn[:, ky:ky + st * (oh - 1) + 1:st, kx:kx + st * (ow - 1) + 1:st, :] for ky in range(kh) for kx in range(kw)], dim=3)
+    g2 = gn.reshape(b * oh * ow, co)
+    x2 = cols.reshape(b * oh * ow, kh * kw * ci)
+    if g2.dtype == torch.float32:
+        res = torch.mm(g2.t(), x2)
+    else:
+        try:
+            res = torch.mm(g2.t(), x2, out_dtype=torch.float32)
+        except (TypeError, RuntimeError, NotImplementedError):
+            res = torch.mm(g2.t().float(), x2.float())
+    if out is not None and tuple(out.shape) == tuple(w_shape) and out.is_contiguous(memory_format=CL):
+        out.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).add_(res, alpha=gain)          # (a view: OHWI memory)
+        return out
+    gw = (res * gain).view(co, kh, kw, ci).permute(0, 3, 1, 2)
+    return gw if out is None else out.add_(gw)
+
+
 def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None, out=None):
     """Weight gradient [O,I,KH,KW] (channels_last, i.e. OHWI in memory).  lin scales x, lout scales gy.
     ``out`` (an OHWI-contiguous tensor of that shape): ADD the gradient to it instead of returning a new tensor — the
@@ -379,6 +419,17 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
     L = plan_wgrad(x.shape, gy.shape, g)
+    if TINY_WGRAD_GEMM and (x.dtype == torch.bfloat16 or TINY_WGRAD_GEMM > 1) and not g.reflect \
+            and gy.shape[2] * gy.shape[3] <= (TINY_MAX_PIX if lin is None else TINY_MAX_PIX_MOD) \
+            and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 512 and x.shape[1] >= 64 and gy.shape[1] >= 64:
+        return _tiny_spatial_wgrad(gy, x, g, w_shape, gain, out, lin, lout)
+    if x.dtype == BF and lin is not None and gy.shape[2] * gy.shape[3] <= PRESCALE_MOD_PIX:
+        # small images of a modulated layer (bf16): the kernels apply the per-sample scales to the accumulators, so a split-K block
+        # cannot cross a sample and a 16x16 image gives each block 8 K-steps under a 128x128 atomic epilogue (145 TFLOP/s).
+        # Scale the (few-MB) operands instead and run the unscaled kernel, whose splits are free to span samples.
+        x = (x * lin[:, :, None, None]).to(BF)
+        gy = (gy * lout[:, :, None, None]).to(BF)
+        lin = lout = None
     if x.dtype == torch.float32 and MATH == _lib.F32_B3 and B3_WINO_WGRAD and tuple(w_shape[2:]) == (3, 3) and g.stride == 1 \
             and g.pad == 1:
         b, ci, h, wd = x.shape

@@ -77,6 +77,8 @@ CONV_CASES = [
     # conv_bf16_wgrad3_kernel (tap-fused weight gradient: Cin, Cout % 64 == 0, W % 32 == 0): three strips, several parts per image,
     # a 2 x 2 grid of channel tiles (the cases (2, 64, 128, .., 8, 64) above -- plain and mirror-padded -- take it as well)
     (3, 64, 64, 3, 1, 1, False, 40, 96), (2, 128, 128, 3, 1, 1, False, 16, 32),
+    # many samples of <= 4x4 output pixels: weight gradient as one library GEMM (op/conv.py::_tiny_spatial_wgrad)
+    (300, 64, 96, 3, 1, 1, False, 2, 2), (80, 64, 64, 3, 2, 0, False, 9, 9),
 ]
 
 

@@ -223,6 +223,8 @@ CONV_CASES = [
     (2, 128, 3, 1, 1, 0, False, 32, 32), (2, 3, 32, 1, 1, 0, False, 20, 20), (2, 32, 1, 1, 1, 0, False, 4, 4),
     (2, 1, 32, 1, 1, 0, False, 4, 4), (2, 512, 8, 1, 1, 0, False, 16, 16), (5, 20, 36, 3, 2, 0, False, 17, 17),
     (2, 128, 64, 3, 2, 0, False, 35, 19),       # its input gradient (128 channels out) runs conv_b3_tphase_kernel
+    # many samples of <= 4x4 output pixels: the weight gradient is one library GEMM on a materialised im2col (op/conv.py::_tiny_spatial_wgrad)
+    (300, 64, 96, 3, 1, 1, False, 2, 2), (80, 64, 64, 3, 2, 0, False, 9, 9), (512, 64, 128, 2, 1, 0, False, 2, 2),
 ]
 
 
@@ -245,6 +247,27 @@ def test_conv_random_vs_oracle(ops, case):
     gxd, gwd = torch.autograd.grad(yd, (xd, wd), dev(gy.float(), True))
     assert rel_err(gxd, gx) < GTOL, ("gx", case, rel_err(gxd, gx))
     assert rel_err(gwd, gw) < GTOL, ("gw", case, rel_err(gwd, gw))
+
+
+@pytest.mark.parametrize("case", [(300, 64, 96, 3, 1, 1, False, 2, 2), (80, 64, 64, 3, 2, 0, False, 9, 9), (512, 64, 128, 2, 1, 0, False, 2, 2)])
+def test_tiny_spatial_wgrad_gemm_f32(ops, case, monkeypatch):
+    """The library-GEMM weight gradient of the <= 4x4-pixel layers (default: bf16 activations only) with f32 operands, and
+    accumulating into an existing channels_last gradient buffer."""
+    from ideas_amd.op import conv as convmod
+    from ideas_amd.op.conv_plan import ConvGeom
+    monkeypatch.setattr(convmod, "TINY_WGRAD_GEMM", 2)
+    test_conv_random_vs_oracle(ops, case)
+    B, ci, co, k, s, p, refl, H, W = case
+    g = ConvGeom(k, k, s, p, refl)
+    oh, ow = g.out_size(H, W)
+    x, gy = dev(torch.randn(B, ci, H, W), True), dev(torch.randn(B, co, oh, ow), True)
+    acc0 = dev(torch.randn(co, ci, k, k), True)
+    acc = acc0.clone(memory_format=torch.channels_last)
+    r = convmod.conv_wgrad_raw(gy, x, g, (co, ci, k, k), 0.25, None, None, out=acc)
+    assert r.data_ptr() == acc.data_ptr()
+    monkeypatch.setattr(convmod, "TINY_WGRAD_GEMM", 0)
+    ref = convmod.conv_wgrad_raw(gy, x, g, (co, ci, k, k), 0.25, None, None)
+    assert rel_err(acc - acc0, ref) < GTOL
 
 
 @pytest.mark.parametrize("case", [(2, 16, 24, 1, 2, 7, 7), (2, 64, 32, 1, 2, 16, 16), (2, 32, 48, 3, 2, 9, 9), (1, 8, 8, 3, 1, 5, 5),
