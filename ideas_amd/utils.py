@@ -9,6 +9,7 @@ explicitly so a step can be replayed without emulating three interleaved RNG str
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import List, Optional, Sequence, Tuple
 
@@ -79,6 +80,9 @@ def g_nonsaturating_loss(fake_pred):
     return F.softplus(-fake_pred).mean()
 
 
+_PATCHIFY_HIP = os.environ.get("IDEAS_PATCHIFY_HIP", "1") != "0"      # 0: one F.interpolate per box (A/B only)
+
+
 def draw_boxes(height: int, width: int, n_crop: int, min_size: float = 1 / 8, max_size: float = 1 / 4) -> List[Box]:
     """The random half of ``patchify_image``: sizes from the torch CPU generator, offsets from ``random``."""
     size = torch.rand(n_crop) * (max_size - min_size) + min_size
@@ -95,6 +99,9 @@ def patchify_image(img: torch.Tensor, n_crop: int, min_size: float = 1 / 8, max_
     if boxes is None:
         boxes = draw_boxes(h, w, n_crop, min_size, max_size)
     th, tw = int(h * max_size), int(w * max_size)
+    if img.is_cuda and c in (1, 3) and len(boxes) <= 64 and _PATCHIFY_HIP:      # one launch for all boxes (csrc/patchify.hip)
+        from .op.patchify import patch_resize
+        return patch_resize(img, boxes, (th, tw))
     patches = [F.interpolate(img[:, :, y:y + ch, x:x + cw], size=(th, tw), mode="bilinear", align_corners=False)
                for (y, x, ch, cw) in boxes]
     return torch.stack(patches, 1).reshape(-1, c, th, tw)

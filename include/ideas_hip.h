@@ -337,6 +337,19 @@ int ideas_adam_ema(float* p, const float* g, float* v, float* ema, int64_t n, fl
 int ideas_image_u8_to_f32(float* y, const void* x_u8, const void* flip_u8, int B, int H, int W, int C, float mean, float stdv,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * patchify_image (utils.py:127-149), device side: crop `n_crop` boxes (host int[n_crop][4] = y, x, h, w in source pixels, the
+ * same boxes for every image, n_crop <= 64) out of x [B][H][W][C] (NHWC, C = 3 or 1; f32 or bf16) and resize each bilinearly
+ * (F.interpolate(mode="bilinear", align_corners=False)) to out_h x out_w.  y: [B * n_crop][out_h][out_w][C], image-major (the
+ * torch.stack(patches, 1).view(B * n_crop, ...) order of utils.py:147-149), x's dtype.  One launch for all boxes.
+ * ideas_patch_resize_bwd: gx f32 [B][H][W][C] += the adjoint applied to gy (y's shape and dtype); `clear` != 0 zeroes gx first.
+ * Overlapping crops accumulate with f32 atomics (the summation order is not fixed, as in torch's own backward).
+ * (additive since ABI version 3.) */
+int ideas_patch_resize(void* y, const void* x, const int* boxes, int n_crop, int B, int C, int H, int W, int out_h, int out_w,
+                       int dtype, void* stream);
+int ideas_patch_resize_bwd(float* gx, const void* gy, const int* boxes, int n_crop, int B, int C, int H, int W, int out_h,
+                           int out_w, int clear, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

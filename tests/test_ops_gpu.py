@@ -1247,3 +1247,61 @@ def test_grad_sink_modulated_conv_and_linear(ops):
     torch.cuda.synchronize()
     for p, g in zip(params, ref):
         assert rel_err(p.grad, 2 * g) < 3e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# patchify_image's crop + bilinear resize (utils.py:127-149) on ideas_patch_resize (csrc/patchify.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def test_patchify_golden(ops_golden):
+    from ideas_amd.utils import patchify_image
+    g = ops_golden
+    boxes = [tuple(int(v) for v in b) for b in g.t("patch.boxes").tolist()]
+    for cl in (False, True):
+        got = patchify_image(dev(g.t("patch.img"), cl), len(boxes), boxes=boxes)
+        assert got.shape == g.t("patch.out").shape
+        assert rel_err(got, g.t("patch.out")) < 1e-6
+
+
+@pytest.mark.parametrize("case", [(2, 3, 64, 64, 8), (3, 3, 40, 72, 5), (2, 1, 32, 32, 3), (1, 3, 256, 256, 32), (2, 3, 16, 16, 64)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_patchify_random_vs_oracle(case, bf16):
+    """Random boxes (full-image, single-row / single-column and minimum-size crops included): forward and the gradient
+    w.r.t. the image against the f64 oracle; image-major stacking order."""
+    import random
+    from ideas_amd.utils import patchify_image
+    B, C, H, W, n = case
+    torch.manual_seed(B * 100 + H + n)
+    rnd = random.Random(H * 7 + n)
+    x = torch.randn(B, C, H, W, dtype=torch.float64)
+    if bf16:
+        x = x.bfloat16().double()
+    boxes = [(0, 0, H, W), (H - 1, 0, 1, W), (0, W - 1, H, 1), (H // 2, W // 2, 1, 1)][:min(4, n)]
+    while len(boxes) < n:
+        ch, cw = rnd.randrange(1, H // 2 + 1), rnd.randrange(1, W // 2 + 1)
+        boxes.append((rnd.randrange(0, H - ch + 1), rnd.randrange(0, W - cw + 1), ch, cw))
+    xr = x.clone().requires_grad_(True)
+    ref = O.patchify_boxes(xr, boxes)
+    gy = torch.randn_like(ref)
+    (gref,) = torch.autograd.grad(ref, xr, gy)
+    adt = torch.bfloat16 if bf16 else torch.float32
+    xd = dev(x.to(adt), True).requires_grad_(True)
+    got = patchify_image(xd, n, boxes=boxes)
+    assert got.shape == ref.shape and got.dtype == adt and got.is_contiguous(memory_format=torch.channels_last)
+    tol = 6e-3 if bf16 else TOL        # (the oracle forms the source index and the weights in f64)
+    assert rel_err(got, ref) < tol, rel_err(got, ref)
+    gyd = gy.bfloat16() if bf16 else gy.float()
+    (gx,) = torch.autograd.grad(got, xd, dev(gyd, True))
+    (gref2,) = torch.autograd.grad(O.patchify_boxes(xr, boxes), xr, gyd.double())
+    assert gx.shape == x.shape and gx.dtype == adt
+    assert rel_err(gx, gref2) < (6e-3 if bf16 else 1e-5), rel_err(gx, gref2)
+
+
+def test_patchify_errors():
+    from ideas_amd.op.patchify import patch_resize
+    x = dev(torch.randn(1, 3, 8, 8), True)
+    with pytest.raises(RuntimeError):
+        patch_resize(x, [(4, 4, 5, 2)], (4, 4))            # box leaves the image
+    with pytest.raises(RuntimeError):
+        patch_resize(x, [(0, 0, 2, 2)] * 65, (4, 4))        # more boxes than one launch carries
+    with pytest.raises(RuntimeError):
+        patch_resize(torch.randn(1, 3, 8, 8), [(0, 0, 2, 2)], (4, 4))   # CPU tensor: no fallback
