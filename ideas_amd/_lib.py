@@ -93,6 +93,7 @@ _PROTOS = {
     "ideas_reflect_fold": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_adam_ema": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "ideas_image_u8_to_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
+    "ideas_channel_sum": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_patch_resize": (C.c_int, [_P, _P, C.POINTER(C.c_int)] + [C.c_int] * 8 + [_P]),
     "ideas_patch_resize_bwd": (C.c_int, [_P, _P, C.POINTER(C.c_int)] + [C.c_int] * 9 + [_P]),
     "ideas_sizeof_prep_desc": (C.c_int, []),

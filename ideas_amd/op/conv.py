@@ -664,6 +664,32 @@ def fork_conv2d(input: torch.Tensor, weight: torch.Tensor, padding: int = 0, gai
     return _ForkConv.apply(to_act(input), weight, g, float(gain))
 
 
+_BIAS_SUM_HIP = _os.environ.get("IDEAS_BIAS_SUM_HIP", "1") != "0"      # 0: autograd's composite sum (A/B only)
+
+
+class _AddBias(Function):
+    """y + bias[c] with the bias gradient on ``ideas_channel_sum`` (autograd's sum over (0, 2, 3) of a channels_last tensor with
+    C = 3 ran as ONE block: 1.0 ms per G.to_rgb backward).  Under create_graph the backward is the differentiable composite."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        ctx.bias_ref = bias
+        return y + bias.view(1, -1, 1, 1).to(y.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gb = None
+        if ctx.needs_input_grad[1]:
+            if torch.is_grad_enabled() or not _BIAS_SUM_HIP:
+                gb = gy.sum((0, 2, 3)).to(ctx.bias_ref.dtype)
+            else:
+                from .fused_act import bias_sink, channel_sum
+                tgt = bias_sink(ctx.bias_ref)
+                gb = channel_sum(gy, into=tgt)
+                gb = None if gb is None else gb.to(ctx.bias_ref.dtype)
+        return gy, gb
+
+
 def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
            padding: int = 0, reflect: bool = False, gain: float = 1.0, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``gain * F.conv2d(input, weight, stride, padding) + bias`` (zero padding, or mirror padding if ``reflect``);
@@ -676,7 +702,7 @@ def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         return _ConvAdd.apply(to_act(input), weight, to_act(resid), g, float(gain))
     y = _Conv.apply(to_act(input), weight, g, float(gain))
     if bias is not None:
-        y = y + bias.view(1, -1, 1, 1)
+        y = _AddBias.apply(y, bias)
     return y
 
 
@@ -809,5 +835,5 @@ def conv_transpose2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[t
     g = ConvGeom(weight.shape[2], weight.shape[3], stride, 0, False)
     y = _ConvT.apply(to_act(input), weight, g, float(gain))
     if bias is not None:
-        y = y + bias.view(1, -1, 1, 1)
+        y = _AddBias.apply(y, bias)
     return y

@@ -86,6 +86,26 @@ def bias_act_raw(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[to
     return (y, bg) if want_bias_grad else y
 
 
+def channel_sum(x: torch.Tensor, into: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """Per-channel sum of [B, C, ...] as f32 [C] on ``ideas_channel_sum`` (any C); ``into`` (contiguous f32 [C]): accumulate there
+    and return None."""
+    _lib.require_cuda(x)
+    dt = _lib.act_dtype(x)
+    if x.dim() == 4:
+        x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+    elif x.dim() == 2:
+        x = x.contiguous()
+    else:
+        raise RuntimeError("channel_sum expects [B, C] or [B, C, H, W]")
+    c = x.shape[1]
+    out = into if into is not None else torch.empty(c, device=x.device, dtype=torch.float32)
+    if x.numel() == 0:
+        return None if into is not None else out.zero_()
+    rc = _lib.load().ideas_channel_sum(_lib.ptr(out), _lib.ptr(x), x.numel(), c, int(into is None), dt, _lib.stream_ptr())
+    _lib.check(rc, "ideas_channel_sum")
+    return None if into is not None else out
+
+
 def bias_sink(bias: Optional[torch.Tensor]):
     """Inside ``grad_sink`` (op/conv.py) and a plain backward: the bias parameter's gradient buffer to accumulate into."""
     if bias is None:

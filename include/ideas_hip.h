@@ -73,6 +73,11 @@ int ideas_fused_bias_act(void* y, const void* x, const void* b, const void* ref,
                          int64_t n, int C, int64_t inner, int layout,
                          int act, int grad, float alpha, float scale, int dtype, void* stream);
 
+/* Per-channel sum of a channels-innermost tensor (x: n elements, NHWC or [B,C]; any C <= 8192): out[c] (+)= sum of x[.., c].
+ * The gradient of a plain conv bias (EqualConv2d with bias and no activation = G.to_rgb, stylegan2/model.py:94-123,
+ * models.py:120), which autograd takes as grad.sum((0, 2, 3)).  `clear` != 0 zeroes out[0..C) first.  (additive since ABI 3.) */
+int ideas_channel_sum(float* out, const void* x, int64_t n, int C, int clear, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * upfirdn2d.  Replaces upfirdn2d_op (upfirdn2d_kernel.cu:209-368): zero-stuff by `up`, pad (negative pad
  * crops), correlate with the FLIPPED kh x kw FIR, decimate by `down`.  x is [B,C,in_h,in_w] (NCHW) or

@@ -1305,3 +1305,48 @@ def test_patchify_errors():
         patch_resize(x, [(0, 0, 2, 2)] * 65, (4, 4))        # more boxes than one launch carries
     with pytest.raises(RuntimeError):
         patch_resize(torch.randn(1, 3, 8, 8), [(0, 0, 2, 2)], (4, 4))   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 64, 64), (2, 1, 5, 7), (3, 7, 9, 4), (2, 64, 8, 8), (5, 300, 3, 3), (16, 3), (1, 3, 1, 1)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_channel_sum(shape, bf16):
+    from ideas_amd.op.fused_act import channel_sum
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape, dtype=torch.float64)
+    x = x.bfloat16().double() if bf16 else x.float().double()
+    ref = x.sum(dim=[d for d in range(x.dim()) if d != 1])
+    xd = dev(x.bfloat16() if bf16 else x.float(), True)
+    got = channel_sum(xd)
+    assert got.dtype == torch.float32 and rel_err(got, ref) < 2e-6
+    acc0 = torch.randn(shape[1], device="cuda")
+    acc = acc0.clone()
+    assert channel_sum(xd, into=acc) is None
+    assert rel_err(acc - acc0, ref) < 2e-6
+    if len(shape) == 4:                                       # NCHW-contiguous input: same answer
+        assert rel_err(channel_sum(dev(x.bfloat16() if bf16 else x.float(), False)), ref) < 2e-6
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_conv_bias_gradient_small_channel_count(ops, transposed):
+    """G.to_rgb (1x1, 128 -> 3, bias, no activation): the bias gradient runs on ideas_channel_sum; first and second order."""
+    torch.manual_seed(5)
+    x = torch.randn(4, 16, 12, 12, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(*((16, 3, 1, 1) if transposed else (3, 16, 1, 1)), dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(3, dtype=torch.float64).requires_grad_(True)
+    y = (F.conv_transpose2d(x, w * 0.25, b, stride=2) if transposed else F.conv2d(x, w * 0.25, b))
+    gy = torch.randn_like(y)
+    gref = torch.autograd.grad(y, (x, w, b), gy)
+    xd, wd, bd = (dev(t.float(), True).requires_grad_(True) for t in (x, w, b))
+    yd = (ops.conv_transpose2d(xd, wd, bd, stride=2, gain=0.25) if transposed else ops.conv2d(xd, wd, bd, gain=0.25))
+    assert rel_err(yd, y) < TOL
+    got = torch.autograd.grad(yd, (xd, wd, bd), dev(gy.float(), True), create_graph=False)
+    for a, r in zip(got, gref):
+        assert rel_err(a, r) < GTOL
+    # create_graph: the composite backward, differentiable (gradient penalty of a sum of squares of the output gradient w.r.t. x)
+    yd2 = (ops.conv_transpose2d(xd, wd, bd, stride=2, gain=0.25) if transposed else ops.conv2d(xd, wd, bd, gain=0.25))
+    (g1,) = torch.autograd.grad(yd2.square().sum(), xd, create_graph=True)
+    (gb2,) = torch.autograd.grad(g1.square().sum(), bd)
+    y2 = (F.conv_transpose2d(x, w * 0.25, b, stride=2) if transposed else F.conv2d(x, w * 0.25, b))
+    (r1,) = torch.autograd.grad(y2.square().sum(), x, create_graph=True)
+    (rb2,) = torch.autograd.grad(r1.square().sum(), b)
+    assert rel_err(gb2, rb2) < GTOL
