@@ -226,8 +226,12 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         fake_patch = patchify_image(hat_X2, args.n_crop, boxes=draws.boxes_d_fake)
         real_patch = patchify_image(X, args.n_crop, boxes=draws.boxes_d_real)
         ref_patch = patchify_image(X, args.ref_crop * args.n_crop, boxes=draws.boxes_d_ref)
-        fake_tex, ref_input = T["Dco"](fake_patch, ref_patch, ref_batch=args.ref_crop)
-        real_tex, _ = T["Dco"](real_patch, ref_input=ref_input)
+        pair = getattr(T["Dco"], "forward_pair", None)
+        if pair is not None:         # one encoder pass over the 8B + 8B + 32B patches (same values; models.py)
+            fake_tex, real_tex, ref_input = pair(fake_patch, real_patch, ref_patch, args.ref_crop)
+        else:
+            fake_tex, ref_input = T["Dco"](fake_patch, ref_patch, ref_batch=args.ref_crop)
+            real_tex, _ = T["Dco"](real_patch, ref_input=ref_input)
         losses["D_texture_loss"] = d_logistic_loss(real_tex, fake_tex)
         d_total = d_total + losses["D_texture_loss"]
     losses["D_dist_loss"] = d_logistic_loss(T["Ddist"](T2), T["Ddist"](T1))

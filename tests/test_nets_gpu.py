@@ -90,6 +90,34 @@ def test_cooccurrence_discriminator(nets_golden):
     _check(nets_golden, "Dco", net, fwd=lambda a, r: net(a, r, ref_batch=2)[0], r1_input=0)
 
 
+def test_cooccurrence_discriminator_batched_encoder(nets_golden, monkeypatch):
+    """``forward_pair`` (one encoder pass over fake + real + reference patches: the D phase of the product's step) against the
+    reference's two calls with separate encoder passes (train.py:88-90): logits, reference features, parameter and input gradients."""
+    import ideas_amd.models as M
+    net = _load(nets_golden, "Dco", "CooccurenceDiscriminator", tiny(256))
+    torch.manual_seed(11)
+    fake = torch.randn(4, 3, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    real = torch.randn(4, 3, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    ref = torch.randn(8, 3, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    params = [p for p in net.parameters()]
+
+    def two_calls():
+        a, ri = net(fake, ref, ref_batch=2)
+        b, _ = net(real, ref_input=ri)
+        return a, b, ri
+
+    monkeypatch.setattr(M, "BATCH_DCO", False)
+    a0, b0, r0 = two_calls()
+    g0 = torch.autograd.grad((a0 * 1.5).sum() - b0.sum(), [fake] + params)
+    monkeypatch.setattr(M, "BATCH_DCO", True)
+    for fn in (two_calls, lambda: net.forward_pair(fake, real, ref, 2)):
+        a1, b1, r1 = fn()
+        assert rel_err(a1, a0) < 1e-5 and rel_err(b1, b0) < 1e-5 and rel_err(r1, r0) < 1e-5
+        g1 = torch.autograd.grad((a1 * 1.5).sum() - b1.sum(), [fake] + params)
+        for u, v in zip(g1, g0):
+            assert rel_err(u, v) < 1e-4
+
+
 def test_image_discriminator_from_seed(nets_golden):
     from ideas_amd.models import init_model
     g = nets_golden

@@ -34,6 +34,24 @@ SHAPES = [
 ]
 
 
+# the co-occurrence discriminator's patch encoder (models.py:379-426) on 64x64 patches; batch multiplier 32 = the 32B reference patches
+SHAPES_DCO = [
+    ("Dco.1.conv1 32->64 @64", 32, 64, 3, 1, 1, False, 64, 32, False, "conv"),
+    ("Dco.1.conv2 64->64 s2 @65", 64, 64, 3, 2, 0, False, 65, 32, False, "conv"),
+    ("Dco.2.conv1 64->128 @32", 64, 128, 3, 1, 1, False, 32, 32, False, "conv"),
+    ("Dco.2.conv2 128->128 s2 @33", 128, 128, 3, 2, 0, False, 33, 32, False, "conv"),
+    ("Dco.3.conv1 128->256 @16", 128, 256, 3, 1, 1, False, 16, 32, False, "conv"),
+    ("Dco.3.conv2 256->256 s2 @17", 256, 256, 3, 2, 0, False, 17, 32, False, "conv"),
+    ("Dco.4.conv1 256->384 @8", 256, 384, 3, 1, 1, False, 8, 32, False, "conv"),
+    ("Dco.4.conv2 384->384 s2 @9", 384, 384, 3, 2, 0, False, 9, 32, False, "conv"),
+    ("Dco.5.conv1 384->384 @4", 384, 384, 3, 1, 1, False, 4, 32, False, "conv"),
+    ("Dco.6.conv1 384->768 @2", 384, 768, 3, 1, 1, False, 2, 32, False, "conv"),
+    ("Dco.6.conv2 768->768 @2", 768, 768, 3, 1, 1, False, 2, 32, False, "conv"),
+    ("Dco.1.skip 1x1 s2 32->64 @63", 32, 64, 1, 2, 0, False, 63, 32, False, "conv"),
+    ("Dco.2.skip 1x1 s2 64->128 @31", 64, 128, 1, 2, 0, False, 31, 32, False, "conv"),
+]
+
+
 def timeit(fn, reps):
     for _ in range(2):
         fn()
@@ -52,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--set", choices=["main", "dco"], default="main", help="layer list: the step's FLOP carriers, or Dco's patch encoder")
     ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS probe: same work, lower power)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="activation dtype (bf16: csrc/conv_bf16.hip)")
     ap.add_argument("--cfg", type=int, default=-1, help="bf16 forward-family tile shape A/B (ideas_tune_bf16_fwd in csrc/conv_bf16.hip)")
@@ -74,7 +93,7 @@ def main():
     tot_f = tot_t = 0.0
     from ideas_amd.op import conv_plan
     conv_plan.cache_begin()          # as inside train_iteration: derived weights (split planes / bf16 packs) are made once
-    for (name, ci, co, k, s, p, refl, H, bm, mod, kind) in SHAPES:
+    for (name, ci, co, k, s, p, refl, H, bm, mod, kind) in (SHAPES_DCO if a.set == "dco" else SHAPES):
         if a.only and a.only not in name:
             continue
         B = a.batch * bm
