@@ -401,6 +401,10 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
 // (Tried for the 64-channel N tile as well -- 8 waves, one accumulator column each: 10-20 % SLOWER than the 4-wave kernel above at
 // three blocks per CU (Dreal.1.conv1's input gradient 236 -> 215 TFLOP/s, E.1.conv1 145 -> 117): with half the MFMAs per staged row
 // the single block per CU is latency-bound.  32 < Cout <= 64 stays on the 4-wave kernel.)
+// (Tried: THREE weight register sets, set ky refilled for (chunk + 1, ky) right behind the MFMAs that read it, so every weight load
+// is in flight for a whole chunk instead of one sub-step -- 242 registers, no spill, counted waits of vmcnt(17..18); 1.5-3 % SLOWER
+// on the 128..512-channel layers (same box: 227.7 -> 224.4, 273.9 -> 266.3, 299.7 -> 289.7 TFLOP/s).  The weight loads cost issue
+// slots and L2 bandwidth, not latency: one sub-step of prefetch distance already covers it.)
 // ---------------------------------------------------------------------------------------------------------------
 template <bool SCALE, bool REFLECT, int TP>
 __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restrict__ y, const float* __restrict__ x,
