@@ -870,6 +870,7 @@ def test_batched_weight_refill_is_bitwise_the_single_launches():
         assert not torch.equal(a.view(torch.int16), c.view(torch.int16))     # (the update did change them)
     conv_plan._RECORDED.clear()                           # (what this test remembered must not leak into later tests' refills)
     conv_plan._PREP_STATE.clear()
+    conv_plan._KEYS_OF.clear()
 
 
 def test_b3_transposed_phases_full_size(monkeypatch):
