@@ -513,12 +513,18 @@ def _sink_target(w: torch.Tensor):
     return gr.as_strided(w.shape, w.stride())
 
 
+_SIDE_STREAM = _os.environ.get("IDEAS_SIDE_STREAM", "1") != "0"
+
+
 def weight_grad(w: torch.Tensor, compute, *uses):
     """``compute(out)`` -> the gradient of ``w`` (added to ``out`` when that is not None).  Returns it, or None after
     sinking it into ``w.grad`` on the side stream (``uses``: the tensors the kernels read, for the allocator)."""
     tgt = _sink_target(w)
     if tgt is None:
         return compute(None)
+    if not _SIDE_STREAM:                 # (A/B only: same in-place accumulation, on the current stream)
+        compute(tgt)
+        return None
     side, cur = _SINK["stream"], torch.cuda.current_stream()
     side.wait_stream(cur)
     for t in uses:
