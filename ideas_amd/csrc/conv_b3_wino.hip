@@ -94,6 +94,71 @@ __global__ __launch_bounds__(256) void wino_split_weights_batched_kernel(const i
 // NH = 2: 512 threads, tile 64 pairs x 128 channels, K-step 32 channels (8 waves  = 4 components x 2 channel halves):
 //         the same window transform + split now feeds twice the products (3.3 instead of 6.6 vector instructions per
 //         MFMA) and there is one barrier per 48 MFMAs; one block per CU (96 KB LDS), two waves per SIMD.
+// Epilogue tail shared by the Winograd kernels: four consecutive channels n..n+3 of one pair row from the four component values
+// (inverse transform, gain / demodulation / bias / activation / residual in the op order of the unfused kernels), stored as ONE
+// 16-byte store per pixel when the row is 16-byte addressable (`vec`: Cout % 4 == 0 and aligned pointers) -- the element-wise form
+// was 32 global_store_dword per thread whose lanes hit 4-byte pieces 32 bytes apart (12 us of a 40 us tile at 256x256).
+__device__ __forceinline__ void wino_finish4(float* __restrict__ y, const float* __restrict__ resid, const float* __restrict__ out_scale,
+                                             const float* __restrict__ bias, const ideas_conv_params& p, const float (&mm)[4][4],
+                                             int64_t opix, int pb, int n, bool vec) {
+    if (vec) {
+        float osv[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (out_scale) {
+            const float4 t4 = *reinterpret_cast<const float4*>(out_scale + (int64_t)pb * p.Cout + n);
+            osv[0] = t4.x; osv[1] = t4.y; osv[2] = t4.z; osv[3] = t4.w;
+        }
+        if (bias) {
+            const float4 t4 = *reinterpret_cast<const float4*>(bias + n);
+            bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+        }
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int64_t yi = opix + (int64_t)px * p.Cout + n;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float o2 = px == 0 ? (mm[0][e] + mm[1][e]) + mm[2][e] : (mm[1][e] - mm[2][e]) - mm[3][e];
+                float t = mul_rn(o2, p.gain);
+                if (out_scale) t = mul_rn(t, osv[e]);
+                t = mul_then_add(t, 1.0f, bv[e]);
+                if (p.act) t = (t > 0.f ? t : t * p.alpha) * p.act_gain;
+                v[e] = t;
+            }
+            if (resid) {
+                const float4 r4 = *reinterpret_cast<const float4*>(resid + yi);
+                v[0] = (v[0] + r4.x) * p.resid_gain; v[1] = (v[1] + r4.y) * p.resid_gain;
+                v[2] = (v[2] + r4.z) * p.resid_gain; v[3] = (v[3] + r4.w) * p.resid_gain;
+            }
+            if (p.accumulate) {
+                const float4 o4 = *reinterpret_cast<const float4*>(y + yi);
+                v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
+            }
+            *reinterpret_cast<float4*>(y + yi) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (n + e >= p.Cout) continue;
+        const float o2[2] = {(mm[0][e] + mm[1][e]) + mm[2][e], (mm[1][e] - mm[2][e]) - mm[3][e]};
+        const float os = out_scale ? out_scale[(int64_t)pb * p.Cout + n + e] : 1.f;
+        const float bvv = bias ? bias[n + e] : 0.f;
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            float v = mul_rn(o2[px], p.gain);
+            if (out_scale) v = mul_rn(v, os);
+            v = mul_then_add(v, 1.0f, bvv);
+            if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+            const int64_t yi = opix + (int64_t)px * p.Cout + n + e;
+            if (resid) v = (v + resid[yi]) * p.resid_gain;
+            if (p.accumulate) y[yi] += v; else y[yi] = v;
+        }
+    }
+}
+__device__ __forceinline__ bool wino_vec_ok(const float* y, const float* resid, const float* out_scale, const float* bias, int Cout) {
+    return (Cout & 3) == 0 && (((uintptr_t)y | (uintptr_t)resid | (uintptr_t)out_scale | (uintptr_t)bias) & 15) == 0;
+}
+
 template <bool SCALE, bool REFLECT, int NH>
 __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                               const void* __restrict__ uplanes,
@@ -332,6 +397,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
 
     // ---- epilogue: the four components meet in LDS, inverse transform, fused gain / demod / bias / act / residual -----
     float* exch = reinterpret_cast<float*>(smem);       // [NH halves][4 v][64 rows][XROW]
+    const bool vec = wino_vec_ok(y, resid, out_scale, bias, p.Cout);
     const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;   // this thread finishes 8 channels of pair row er, half eh
     const bool row_live = m0 + er < M;
     int pb = 0;
@@ -364,23 +430,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
                     const float4 m3v = *reinterpret_cast<const float4*>(ex + 3 * WP * XROW);
                     const float mm[4][4] = {{m0v.x, m0v.y, m0v.z, m0v.w}, {m1v.x, m1v.y, m1v.z, m1v.w},
                                             {m2v.x, m2v.y, m2v.z, m2v.w}, {m3v.x, m3v.y, m3v.z, m3v.w}};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.Cout) continue;
-                        const float o2[2] = {(mm[0][e] + mm[1][e]) + mm[2][e], (mm[1][e] - mm[2][e]) - mm[3][e]};
-                        const float os = out_scale ? out_scale[(int64_t)pb * p.Cout + n + e] : 1.f;
-                        const float bvv = bias ? bias[n + e] : 0.f;
-#pragma unroll
-                        for (int px = 0; px < 2; ++px) {
-                            float v = mul_rn(o2[px], p.gain);
-                            if (out_scale) v = mul_rn(v, os);
-                            v = mul_then_add(v, 1.0f, bvv);
-                            if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
-                            const int64_t yi = opix + (int64_t)px * p.Cout + n + e;
-                            if (resid) v = (v + resid[yi]) * p.resid_gain;
-                            if (p.accumulate) y[yi] += v; else y[yi] = v;
-                        }
-                    }
+                    wino_finish4(y, resid, out_scale, bias, p, mm, opix, pb, n, vec);
                 }
             }
         }
@@ -585,6 +635,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
         gloadB(fb0);
     };
     float* exch = reinterpret_cast<float*>(smem);
+    const bool vec = wino_vec_ok(y, resid, out_scale, bias, p.Cout);
     const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;
     int d = blockIdx.x;
     begin_tile(d);
@@ -632,23 +683,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
                 const float4 m3v = *reinterpret_cast<const float4*>(ex + 3 * WP * XROW);
                 const float mm[4][4] = {{m0v.x, m0v.y, m0v.z, m0v.w}, {m1v.x, m1v.y, m1v.z, m1v.w},
                                         {m2v.x, m2v.y, m2v.z, m2v.w}, {m3v.x, m3v.y, m3v.z, m3v.w}};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (n + e >= p.Cout) continue;
-                    const float o2[2] = {(mm[0][e] + mm[1][e]) + mm[2][e], (mm[1][e] - mm[2][e]) - mm[3][e]};
-                    const float os = out_scale ? out_scale[(int64_t)e_pb * p.Cout + n + e] : 1.f;
-                    const float bvv = bias ? bias[n + e] : 0.f;
-#pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        float v = mul_rn(o2[px], p.gain);
-                        if (out_scale) v = mul_rn(v, os);
-                        v = mul_then_add(v, 1.0f, bvv);
-                        if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
-                        const int64_t yi = opix + (int64_t)px * p.Cout + n + e;
-                        if (resid) v = (v + resid[yi]) * p.resid_gain;
-                        if (p.accumulate) y[yi] += v; else y[yi] = v;
-                    }
-                }
+                wino_finish4(y, resid, out_scale, bias, p, mm, opix, e_pb, n, vec);
             }
         }
         __syncthreads();
