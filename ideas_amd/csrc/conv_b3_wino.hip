@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     // chunk c: LDS[c&1] holds its planes, `fbA` the weights of (c, ky 0); chunk c+1's window is in `stg` (transformed + split into
     // LDS[(c+1)&1] under the first MFMAs), chunk c+2's window is fetched into `ld`; the weights of every sub-step are fetched one
     // sub-step ahead.  The sets swap roles every chunk (3 sub-steps), so the loop body is two chunks.
-    auto step = [&](int c, Stage& ld, const Stage& stg, BFrag& fbA, BFrag& fbB) {
+    auto step_plain = [&](int c, Stage& ld, const Stage& stg, BFrag& fbA, BFrag& fbB) {      // TP < 32 (234-238 registers already)
         const unsigned char* base = smem + (c & 1) * BUFB;
         gloadB(fbB);                                       // (c, ky 1): first in the vmcnt queue, wanted soonest
         gloadA(ld);
@@ -624,6 +624,33 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
         }
         __syncthreads();
     };
+    // TP = 32 (207 registers before, 235-245 with this; the narrower patches would spill):
+    // The operand reads run one sub-step ahead of the MFMAs that use them (two register sets, `faX` = the fragments of (c, ky 0),
+    // already loaded): a sub-step no longer starts with six ds_read_b128 and a wait for them.  The chunk's ONE barrier sits in front
+    // of the last sub-step's MFMAs -- by then every wave has finished reading LDS[c&1] (its ky 2 fragments have arrived) and written
+    // its part of LDS[(c+1)&1] -- so the first fragments of chunk c+1 are read under those MFMAs as well.  Same box: 263 -> 269,
+    // 304 -> 312, 318 -> 328 TFLOP/s on the 128 / 256 / 512-channel layers.
+    auto step = [&](int c, Stage& ld, const Stage& stg, BFrag& fbA, BFrag& fbB, bf16x8 (&faX)[2][3], bf16x8 (&faY)[2][3], bool more_chunks) {
+        const unsigned char* base = smem + (c & 1) * BUFB;
+        gloadB(fbB);                                       // (c, ky 1): first in the vmcnt queue, wanted soonest
+        gloadA(ld);
+        __builtin_amdgcn_sched_barrier(0);
+        afrags(base, 1, faY);
+        __builtin_amdgcn_sched_barrier(0);
+        lstoreA((c & 1) ^ 1, transform_split(stg));
+        mfmas(faX, fbA);
+        __builtin_amdgcn_sched_barrier(0);
+        gloadB(fbA);                                       // (c, ky 2)
+        afrags(base, 2, faX);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(faY, fbB);
+        __builtin_amdgcn_sched_barrier(0);
+        gloadB(fbB);                                       // (c + 1, ky 0)
+        __syncthreads();
+        if (more_chunks) afrags(smem + ((c & 1) ^ 1) * BUFB, 0, faY);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(faX, fbA);
+    };
     const int nc = p.Cin / BK;
     BFrag fb0, fb1;
     auto begin_tile = [&](int d) {                         // tile d: addresses, then its first window and weight loads
@@ -650,11 +677,21 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     gloadA(st1);
     __syncthreads();
     int c = 0;
-    for (; c + 1 < nc; c += 2) {
-        step(c, st0, st1, fb0, fb1);
-        step(c + 1, st1, st0, fb1, fb0);
+    if constexpr (TP == 32) {
+        bf16x8 faP[2][3], faQ[2][3];
+        afrags(smem, 0, faP);
+        for (; c + 1 < nc; c += 2) {
+            step(c, st0, st1, fb0, fb1, faP, faQ, true);
+            step(c + 1, st1, st0, fb1, fb0, faQ, faP, c + 2 < nc);
+        }
+        if (c < nc) step(c, st0, st1, fb0, fb1, faP, faQ, false);
+    } else {
+        for (; c + 1 < nc; c += 2) {
+            step_plain(c, st0, st1, fb0, fb1);
+            step_plain(c + 1, st1, st0, fb1, fb0);
+        }
+        if (c < nc) step_plain(c, st0, st1, fb0, fb1);
     }
-    if (c < nc) step(c, st0, st1, fb0, fb1);
 
     // ---- epilogue: as above; pair-row er of the patch = output row y0 + er / TP, pair px0 + er % TP.  The next tile's first
     // loads go out first (the coordinates of THIS tile are copied before set_tile overwrites them) --------------------------------
