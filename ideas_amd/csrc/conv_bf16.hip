@@ -158,6 +158,33 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt immediate");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// The wait in front of a K-step's raw barrier: this wave's DMA pieces of the step have landed (counted vmcnt) AND its LDS reads of
+// the previous step have returned.  The second half matters: hipcc floats `s_barrier` (and a bare vmcnt wait) up over the previous
+// step's last MFMAs and over the `s_waitcnt lgkmcnt` in front of them, so a wave passed the barrier with ds_reads of stage t-1 still
+// queued -- and behind the barrier the other waves' DMA overwrites exactly that stage.  Alone the reads always won that race; next
+// to a kernel that keeps the LDS busy (the f32 split weight gradient on the side stream) the image kernel returned a few output
+// channels off by one K-step in 20 % of its launches (tools/probes/img_vs_b3wgrad.py; cdna_hip_programming.md: "raw s_barrier +
+// lgkmcnt(0)").
+template <int N> __device__ __forceinline__ void wait_step() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+// Register-only widening of the epilogue stores.  In the accumulator layout lane (li, lh) holds, per 32-channel block, the four
+// channel quads 8g + 4lh .. +3 (g = 0..3) of pixel li: 8-byte stores, 64 pieces per instruction.  v_permlane32_swap exchanges
+// lanes li and li + 32 (the two halves of the SAME pixel): swapping quad g of the upper half with quad g + 2 of the lower half
+// leaves lane (li, 0) with channels 0-15 and lane (li, 1) with channels 16-31 of the block -- two 16-byte stores per lane, 32
+// contiguous bytes, half the store instructions, no LDS.  out[c] = channels 8 (c + 2 lh) .. + 7 of the block.  With the stores compiled
+// out the 128-channel image kernel runs 1030 instead of 750 TFLOP/s at 256x256; this form recovers 820 (Dreal.1.conv1 710 -> 780,
+// E.2.conv1 575 -> 840).  (The tile through LDS as whole pixel rows, 128-byte lines per pixel, was the same speed.)
+__device__ __forceinline__ void quad_exchange(const uint2 (&q)[4], uint4 (&out)[2]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const auto rx = __builtin_amdgcn_permlane32_swap(q[g].x, q[g + 2].x, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(q[g].y, q[g + 2].y, false, false);
+        out[g] = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+    }
+}
 
 template <int WM, int WN, int MT, int NT, int NST, bool PERIMG, bool REFLECT>
 __device__ __forceinline__ void conv_bf16_body(bf16_t* __restrict__ y, const bf16_t* __restrict__ x, const void* __restrict__ wpack,
@@ -278,7 +305,7 @@ __device__ __forceinline__ void conv_bf16_body(bf16_t* __restrict__ y, const bf1
     for (int st = 0; st < NST - 1; ++st) fetch(st);               // prologue: tiles 0 .. NST-2
     int st_cur = 0, st_free = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt<(NST - 2) * DMA_PER>();          // this wave's pieces of tile kt have landed
+        wait_step<(NST - 2) * DMA_PER>();           // this wave's pieces of tile kt have landed, its reads of tile kt-1 returned
         __builtin_amdgcn_s_barrier();               // ... and everybody else's; all waves are done with tile kt-1
         fetch(st_free);                             // tile kt+NST-1 into the stage tile kt-1 occupied
         const unsigned char* base = smem + st_cur * BUF;
@@ -324,18 +351,20 @@ __device__ __forceinline__ void conv_bf16_body(bf16_t* __restrict__ y, const bf1
         row_b[t] = b;
     }
     __syncthreads();
+    const bool wide = (p.Cout & 7) == 0 && (((uintptr_t)y) & 15) == 0;      // 16-byte stores after a lane exchange (quad_exchange)
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
         const int row = (wm * MT + a) * 32 + li;
         const int64_t off = row_off[row];
-        if (off < 0) continue;
         const int bimg = row_b[row];
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
+            uint2 q[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                q[g] = make_uint2(0u, 0u);
                 const int n = n0 + (wn * NT + b) * 32 + 8 * g + 4 * lh;
-                if (n >= p.Cout) continue;           // Cout % 4 == 0
+                if (off < 0 || n >= p.Cout) continue;           // Cout % 4 == 0
                 float v[4];
                 const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 os = out_scale ? *reinterpret_cast<const float4*>(out_scale + (int64_t)bimg * p.Cout + n)
@@ -355,7 +384,17 @@ __device__ __forceinline__ void conv_bf16_body(bf16_t* __restrict__ y, const bf1
                     if (p.accumulate) u += pv[j];
                     v[j] = u;
                 }
-                *reinterpret_cast<uint2*>(y + off + n) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                q[g] = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                if (!wide) *reinterpret_cast<uint2*>(y + off + n) = q[g];
+            }
+            if (wide) {                                      // (block-uniform; every lane takes part in the exchange)
+                uint4 ch[2];
+                quad_exchange(q, ch);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int n = n0 + (wn * NT + b) * 32 + 8 * (c + 2 * lh);
+                    if (off >= 0 && n < p.Cout) *reinterpret_cast<uint4*>(y + off + n) = ch[c];
+                }
             }
         }
     }
@@ -545,7 +584,7 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
         // two previous positions (even positions <= 6 carry one)
         constexpr int P1 = (TAP + 7) % 9, P2 = (TAP + 8) % 9;
         constexpr int NFLY = 1 + ((P1 % 2 == 0 && P1 <= 6) ? 1 : 0) + ((P2 % 2 == 0 && P2 <= 6) ? 1 : 0);
-        wait_vmcnt<NFLY>();
+        wait_step<NFLY>();
         __builtin_amdgcn_s_barrier();
         fetchB((TAP + 2) % 3);                                             // weight step + 2 into the stage step - 1 used
         if (TAP % 2 == 0 && TAP <= 6) fetchA((chunk & 1) ^ 1, TAP / 2, chunk + 1);
@@ -600,13 +639,16 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
         row_off[t] = (((int64_t)img * p.YH + y0 + prow) * p.YW + x0 + pcol) * p.Cout;
     }
     __syncthreads();
+    const bool wide = (p.Cout & 7) == 0 && (((uintptr_t)y) & 15) == 0;      // 16-byte stores after a lane exchange (quad_exchange)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int64_t off = row_off[wm * 64 + a * 32 + li];
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
+            uint2 q[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                q[g] = make_uint2(0u, 0u);
                 const int n = n0 + (wn * NT + b) * 32 + 8 * g + 4 * lh;
                 if (n >= p.Cout) continue;           // Cout % 4 == 0
                 float v[4];
@@ -628,7 +670,17 @@ __global__ __launch_bounds__(512, 4) void conv_bf16_img_kernel(bf16_t* __restric
                     if (p.accumulate) u += pv[j];
                     v[j] = u;
                 }
-                *reinterpret_cast<uint2*>(y + off + n) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                q[g] = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                if (!wide) *reinterpret_cast<uint2*>(y + off + n) = q[g];
+            }
+            if (wide) {                                      // (block-uniform; every lane takes part in the exchange)
+                uint4 ch[2];
+                quad_exchange(q, ch);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int n = n0 + (wn * NT + b) * 32 + 8 * (c + 2 * lh);
+                    if (n < p.Cout) *reinterpret_cast<uint4*>(y + off + n) = ch[c];
+                }
             }
         }
     }
