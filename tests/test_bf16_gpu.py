@@ -377,3 +377,33 @@ def test_train_iteration_bf16_tracks_f32():
     agree = float(((df[moved] > 0) == (db[moved] > 0)).float().mean())
     print("bf16 vs f32 step: losses", {k: (round(lb[k], 4), round(v, 4)) for k, v in lf.items()}, "sign agreement %.4f" % agree)
     assert agree > 0.9, agree
+
+
+def test_bf16_image_kernel_reproducible_next_to_lds_heavy_kernel():
+    """Regression: the LDS-image forward kernel repeated while the f32 split weight gradient (register-staged, LDS-heavy) runs on
+    another stream must give bitwise the same tensor every time.  Before the K-step waits of csrc/conv_bf16.hip also retired the
+    wave's own LDS reads (`wait_step`), a wave could pass the step's raw barrier with reads of the previous stage still queued while
+    the other waves' DMA overwrote that stage: ~20 % of such launches had a few output channels off by one K-step."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    torch.manual_seed(3)
+    B, C, R = 4, 128, 256
+    g = ConvGeom(3, 3, 1, 1, False)
+    x = torch.randn(B, C, R, R, device="cuda").to(BF).contiguous(memory_format=CL)
+    x32 = x.float().contiguous(memory_format=CL)
+    gy32 = torch.randn_like(x32)
+    w = torch.randn(C, C, 3, 3, device="cuda").contiguous(memory_format=CL)
+    s = torch.rand(B, C, device="cuda") + 0.5
+    d = torch.rand(B, C, device="cuda") + 0.5
+    gain = 1 / math.sqrt(C * 9)
+    side = torch.cuda.Stream()
+    ref = CV.conv_fwd_raw(x, w, g, gain, s, d)
+    torch.cuda.synchronize()
+    bad = 0
+    for i in range(400):
+        if i % 4 == 0:
+            with torch.cuda.stream(side):
+                CV.conv_wgrad_raw(gy32, x32, g, tuple(w.shape), gain, s, d)
+        bad += int(bool((CV.conv_fwd_raw(x, w, g, gain, s, d) != ref).any()))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 400 launches differ"
