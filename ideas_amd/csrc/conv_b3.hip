@@ -435,8 +435,15 @@ extern "C" int ideas_b3_conv_supported(const ideas_conv_params* p) {
 
 // called by ideas_conv_igemm for dtype IDEAS_F32_B3 once the arguments are validated; `wplanes` comes from
 // ideas_b3_split_weights
+#ifndef SMALL_GRID_TILES
+#define SMALL_GRID_TILES 160
+#endif
 int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
                  const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    // few pixels, many channels (E's texture head on 4x4 .. 7x7 maps, Dco's last blocks on 8B patches): 128 x 128 tiles are fewer
+    // than the CUs -- the 64-channel N tile doubles the blocks (E.texture.1 forward 64 -> 128 blocks)
+    const int64_t t128 = ideas_cdiv((int64_t)p->B * p->OH * p->OW, 128) * ideas_cdiv(p->Cout, 128);
+    if (p->Cout > 64 && t128 < SMALL_GRID_TILES) return launch_b3_cfg<2, 2, 2, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);
     if (p->Cout > 64) return launch_b3_cfg<2, 2, 2, 2>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);  // 128x128
     if (p->Cout > 32) return launch_b3_cfg<2, 2, 2, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);  // 128x64
     return launch_b3_cfg<4, 1, 1, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);                    // 128x32
