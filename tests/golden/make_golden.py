@@ -585,11 +585,22 @@ def gen_step(RM, RU, RL, RO, which):
         R, B, n_iters, zero_dco, N = 256, 1, 2, False, 2
     else:
         R, B, n_iters, zero_dco = 256, 1, 2, False
-    args = tiny_args(R, N=N)
+    d_reg_every = 2
+    width = dict(channel=4, texture_channel=64, cm_den=8)
+    if which == "r256_full":
+        # The bench's architecture (train.py:344-356 defaults: channel 32, texture_channel 2048, multiplier 1) inside ONE iteration
+        # of the unmodified train(), R1 included (d_reg_every = 1): 512-channel layers and the 2048-d texture code inside a
+        # reference-anchored step.  ~2 minutes of CPU; the weights regenerate from the seed, so only draws / losses / norms are stored.
+        n_iters, d_reg_every = 1, 1
+        width = dict(channel=32, texture_channel=2048, cm_den=1)
+        args = ns(channel=32, structure_channel=8, texture_channel=2048, N=N, image_size=R, channel_multiplier=1,
+                  blur_kernel=(1, 3, 3, 1))
+    else:
+        args = tiny_args(R, N=N)
     args.__dict__.update(num_iters=n_iters, start_iter=0, lambda_Ex=10.0, lr=0.002, batch_size=B, real_r1=10.0,
-                         texture_r1=1.0, dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=2,
+                         texture_r1=1.0, dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=d_reg_every,
                          log_every=1, show_every=n_iters, save_every=10 ** 9)
-    seed = {"r64": 77, "r64_N2": 79, "r128": 80, "r256_N2": 81}.get(which, 78)
+    seed = {"r64": 77, "r64_N2": 79, "r128": 80, "r256_N2": 81, "r256_full": 82}.get(which, 78)
     gx = torch.Generator().manual_seed(seed + 100)
     X = torch.rand(B, 3, R, R, generator=gx) * 2 - 1
     trainer, draws, log, losses, test_lines = run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco)
@@ -599,8 +610,8 @@ def gen_step(RM, RU, RL, RO, which):
     else:   # large batches: the replay regenerates X from the seeded generator above and checks these two numbers
         out["X_seed"] = np.array(seed + 100)
         out["X_check"] = np.array([float(X.double().sum()), float(X.double().abs().sum())])
-    out["meta"] = np.array(json.dumps(dict(R=R, B=B, N=N, n_iters=n_iters, zero_dco=zero_dco, d_reg_every=2, channel=4,
-                                           texture_channel=64, cm_den=8, test_lines=test_lines,
+    out["meta"] = np.array(json.dumps(dict(R=R, B=B, N=N, n_iters=n_iters, zero_dco=zero_dco, d_reg_every=d_reg_every,
+                                           test_lines=test_lines, **width,
                                            opt_log=[[n_, len(v)] for n_, v, _ in log])))
     for i, z in enumerate(draws["Z"]):
         out[f"Z{i}"] = npy(z)          # raw U[0,1) draws; the step uses z*2-1
@@ -651,5 +662,7 @@ if __name__ == "__main__":
         gen_step(*mods, "r128")
     if "step_r256_N2" in todo:
         gen_step(*mods, "r256_N2")
+    if "step_r256_full" in todo:        # not in the default list: two minutes of CPU and ~25 GB of peak memory
+        gen_step(*mods, "r256_full")
     if "pathlen" in todo:
         gen_pathlen(*mods)

@@ -113,7 +113,7 @@ def _oracle_trainer(trainer, args):
     return out
 
 
-@pytest.mark.parametrize("which", ["r64", "r256", "r64_N2", "r256_N2"])
+@pytest.mark.parametrize("which", ["r64", "r256", "r64_N2", "r256_N2", "r256_full"])
 def test_product_step_logic_against_reference_train(which):
     """ideas_amd.train_step.train_iteration (host logic) with oracle-backed nets == reference train() vectors."""
     from test_nets_gpu import check_replay, replay_step

@@ -150,8 +150,11 @@ def replay_step(which, device, build_nets=None, fuse=None):
     g = Golden(f"step_{which}.npz")
     meta = g.json("meta")
     R, B = meta["R"], meta["B"]
-    args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=R, batch_size=B,
-                           d_reg_every=2, num_iters=meta["n_iters"], use_dco=True, N=meta.get("N", 1))
+    # width of the fixture's networks: the tiny replay width unless the fixture says otherwise (step_r256_full: the bench's
+    # architecture, channel 32 / texture 2048 / multiplier 1, train.py:344-356)
+    args = TS.default_args(channel=meta.get("channel", 4), texture_channel=meta.get("texture_channel", 64),
+                           channel_multiplier=1.0 / meta.get("cm_den", 8), image_size=R, batch_size=B,
+                           d_reg_every=meta.get("d_reg_every", 2), num_iters=meta["n_iters"], use_dco=True, N=meta.get("N", 1))
     torch.manual_seed(int(g.t("seed")))
     trainer = TS.build_trainer(args, "cpu", init_model, dco_factory=(ZeroDco if meta["zero_dco"] else None))
     if build_nets is not None:
@@ -250,7 +253,7 @@ def check_replay(g, meta, trainer, out, log):
         assert abs(a - a_ref) <= 1e-5 * a_ref + 1e-9, (name, a, a_ref)
 
 
-@pytest.mark.parametrize("which", ["r64", "r256", "r64_N2", "r128", "r256_N2"])
+@pytest.mark.parametrize("which", ["r64", "r256", "r64_N2", "r128", "r256_N2", "r256_full"])
 def test_step_replay_gpu(which):
     g, meta, trainer, out, log = replay_step(which, "cuda")
     check_replay(g, meta, trainer, out, log)
