@@ -22,7 +22,7 @@ from torch import nn
 from .model import (CL, Blur, EqualConv2d, EqualLinear, ScaledLeakyReLU,
                     StyledConv_without_noise as StyledConv)
 from .op import FusedLeakyReLU, conv2d, conv_transpose2d, upfirdn2d
-from .op.conv import fork_conv2d
+from .op.conv import down_pair, down_pair_ok, fork_conv2d
 from .op.upfirdn2d import fork_down2, upfirdn2d_up2_add
 from .precision import to_act, to_f32
 
@@ -32,6 +32,7 @@ FUSE_RESIDUAL_ADDS = True     # big residual blocks: block input forked by one a
 # 454.5 ms, bf16 162.3 -> 161.7 ms -- the 32B-patch pass already fills the chip and the merged pass loses the overlap of one pass's
 # weight gradients (side stream) with the next pass's forward.  OFF by default; IDEAS_BATCH_DCO=1 selects it.
 BATCH_DCO = os.environ.get("IDEAS_BATCH_DCO", "0") == "1"
+FUSE_BLUR_CONV = os.environ.get("IDEAS_BLUR_CONV", "1") != "0"   # downsampling ResBlock body with conv2's Blur inside its conv kernel
 FUSE_BLUR_BACKWARD = True     # ResBlock: conv1 + conv2's Blur as one Function whose backward is one kernel (A/B switch for tools / tests)
 
 
@@ -234,7 +235,42 @@ class ResBlock(nn.Module):
         else:
             self.skip = None
 
+    def _fused_body(self):
+        """(conv1's EqualConv2d, its activation, mirror padding, conv2's Blur, EqualConv2d, activation) when the block's body is
+        [ReflectionPad2d] conv act -> Blur conv(stride 2) act, the shape op.conv.down_pair runs with the Blur inside the conv kernel."""
+        m1, m2 = list(self.conv1), list(self.conv2)
+        refl = 0
+        if len(m1) == 3 and isinstance(m1[0], nn.ReflectionPad2d):
+            refl, m1 = m1[0].padding[0], m1[1:]
+        if not (len(m1) == 2 and isinstance(m1[0], EqualConv2d) and isinstance(m1[1], FusedLeakyReLU) and m1[0].bias is None
+                and m1[0].stride == 1):
+            return None
+        if not (len(m2) == 3 and isinstance(m2[0], Blur) and isinstance(m2[1], EqualConv2d) and isinstance(m2[2], FusedLeakyReLU)
+                and m2[1].bias is None and m2[1].stride == 2 and m2[1].padding == 0):
+            return None
+        return m1[0], m1[1], refl, m2[0], m2[1], m2[2]
+
+    def _body_pair_ok(self, x) -> bool:
+        c1, a1, refl, blur, c2, a2 = self._fused
+        if a1.negative_slope != a2.negative_slope:
+            return False
+        return down_pair_ok(x, c1.weight, c2.weight, blur.kernel, blur.pad, refl if refl else c1.padding)
+
+    def _body_pair(self, x, post_gain: float = 1.0, resid=None):
+        c1, a1, refl, blur, c2, a2 = self._fused
+        pad1, reflect1 = (refl, True) if refl else (c1.padding, False)
+        return down_pair(x, c1.weight, a1.bias, c2.weight, a2.bias, blur.kernel, blur.pad, padding1=pad1, reflect1=reflect1,
+                         gain1=c1.scale, gain2=c2.scale, negative_slope=a1.negative_slope, scale1=a1.scale,
+                         scale2=a2.scale * post_gain, resid=resid)
+
     def forward(self, input):
+        if FUSE_BLUR_CONV and input.is_cuda:
+            if not hasattr(self, "_fused"):
+                self._fused = self._fused_body()
+            if self._fused is not None and self._body_pair_ok(input):
+                # conv1 -> [Blur -> stride-2 conv2] with the Blur inside conv2's kernel (csrc/conv_b3_s2fir.hip); shapes the kernel
+                # does not cover (small maps, bf16 activations) take the layer-by-layer path below
+                return _res_merge(self, lambda x: x, self._body_pair, input)
         if FUSE_BLUR_BACKWARD and torch.is_grad_enabled() and isinstance(self.conv2[0], Blur) and isinstance(self.conv1[-1], FusedLeakyReLU):
             # downsampling block under autograd: conv1 also applies conv2's blur, so that the backward of the pair is one kernel
             # (blur adjoint + leaky-ReLU mask + bias gradient, op.conv._ConvBiasActBlur)

@@ -109,7 +109,9 @@ def _f32(t):
 def bf16_pack(L: Launch, in_scale=None) -> torch.Tensor:
     """bf16 pack of a forward-family weight matrix for ideas_conv_igemm(IDEAS_BF16), read from the parameter through the strides
     of ``L.wview``.  Plain convs: one pack, memoised like the b3 planes.  Modulated convs (in_scale [B, Cin]): one pack per
-    sample, w * in_scale[b] — never cached (it depends on the styles) and freed after the launch."""
+    sample, w * in_scale[b]; memoised on (weights, styles) for the iteration -- G is applied to the same texture code two or three
+    times -- inside a byte budget (conv_plan.STYLE_BUDGET_MB, oldest entries dropped first: the packs of a style that cannot
+    recur, e.g. the D phase's T2, do not stay resident until the G step)."""
     v = L.wview
     nb = 1 if in_scale is None else L.B
 
@@ -123,7 +125,7 @@ def bf16_pack(L: Launch, in_scale=None) -> torch.Tensor:
     if L.wsrc is None:
         return make()
     if in_scale is not None:           # per-sample packs: the same (weights, styles) pair comes back within an iteration (conv_plan.cached_on)
-        return conv_plan.cached_on(L.wsrc, ("bf16s",) + L.wkey, in_scale, make)
+        return conv_plan.cached_on(L.wsrc, ("bf16s",) + L.wkey, in_scale, make, budget=True)
     sn, sty, stx, sc = v.stride()
     unit = sc == 1 and v.data_ptr() % 16 == 0 and sn % 4 == 0 and sty % 4 == 0 and stx % 4 == 0
     prep = (_lib.PREP_BF16_PACK, L.Cout * L.TY * L.TX * L.Cin, (L.Cout, L.TY, L.TX, L.Cin), (sn, sty, stx, sc), unit, v.data_ptr(),
@@ -200,6 +202,9 @@ def launch_multi(y: torch.Tensor, x: torch.Tensor, launches, gain: float, in_sca
     n = len(launches)
     if not B3_MULTI or n < 2 or n > 4:
         return False
+    # heaviest launch first (include/ideas_hip.h: the launches run back to back inside one grid, so the lightest one's tail is the
+    # one left exposed): plan_dgrad hands the parity phases over in (ry, rx) order, e.g. 1 / 2 / 2 / 4 taps for a 3x3 stride-2 pad-1 conv
+    launches = sorted(launches, key=lambda L: -(L.TY * L.TX * L.OH * L.OW))
     lib = _lib.load()
     ps = (_lib.ConvParams * n)(*[_params(L, gain) for L in launches])
     if x.dtype == BF:           # bf16 family (csrc/conv_bf16.hip::conv_bf16_multi_kernel): the launches' packs, per sample when modulated
@@ -675,12 +680,15 @@ _BIAS_SUM_HIP = _os.environ.get("IDEAS_BIAS_SUM_HIP", "1") != "0"      # 0: auto
 
 class _AddBias(Function):
     """y + bias[c] with the bias gradient on ``ideas_channel_sum`` (autograd's sum over (0, 2, 3) of a channels_last tensor with
-    C = 3 ran as ONE block: 1.0 ms per G.to_rgb backward).  Under create_graph the backward is the differentiable composite."""
+    C = 3 ran as ONE block: 1.0 ms per G.to_rgb backward).  Under create_graph the backward is the differentiable composite.
+    The sum follows torch's type promotion: a bf16 activation plus the f32 parameter is an f32 tensor (G's image and Ex's message
+    keep the f32 bias and one rounding, as before this Function existed); the incoming gradient has that dtype."""
 
     @staticmethod
     def forward(ctx, y, bias):
         ctx.bias_ref = bias
-        return y + bias.view(1, -1, 1, 1).to(y.dtype)
+        ctx.y_dtype = y.dtype
+        return y + bias.view(1, -1, 1, 1)
 
     @staticmethod
     def backward(ctx, gy):
@@ -693,7 +701,7 @@ class _AddBias(Function):
                 tgt = bias_sink(ctx.bias_ref)
                 gb = channel_sum(gy, into=tgt)
                 gb = None if gb is None else gb.to(ctx.bias_ref.dtype)
-        return gy, gb
+        return (gy if gy.dtype == ctx.y_dtype else gy.to(ctx.y_dtype)), gb
 
 
 def conv2d(input: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1,
@@ -786,6 +794,188 @@ class _ConvBiasActBlur(Function):
         if ctx.needs_input_grad[1]:
             gw = _wgrad(w, g_pre, x, ctx.g, ctx.gain)
         return gx, gw, (gb if need_b else None), None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------
+# Blur -> 3x3 / stride-2 conv (+ bias + leaky-ReLU) of a downsampling ConvLayer in ONE kernel (csrc/conv_b3_s2fir.hip): the
+# blurred tensor is built in LDS under each output patch and never makes the round trip through HBM.  IDEAS_BLUR_CONV=0 keeps the
+# blur a separate pass (A/B measurements).
+# ----------------------------------------------------------------------------------------------------
+BLUR_CONV = _os.environ.get("IDEAS_BLUR_CONV", "1") != "0"
+BLUR_CONV_MIN_OW = int(_os.environ.get("IDEAS_BLUR_CONV_MIN_OW", "16"))      # below: the 8 x 16 output patch of the kernel would idle
+
+
+def fir_factors(fir: torch.Tensor, flip: bool = True):
+    """Host-side factors (kh[4], kv[4]) of a separable 4x4 FIR, derived the way the stand-alone blur kernel derives them on the
+    device (upfirdn2d.hip::blur4_f32_c2: kh = first row of the flipped table, kv = first column / its first element, in f32), or
+    None for a rank > 1 table.  One synchronising copy per FIR tensor: the tables are constant module buffers (stylegan2/model.py:84)."""
+    hit = getattr(fir, "_ideas_factors", None)
+    if hit is not None and hit[0] == (fir._version, flip, fir.data_ptr()):
+        return hit[1]
+    import numpy as np
+    res = None
+    if tuple(fir.shape) == (4, 4):
+        f = fir.detach().to(torch.float32).cpu().numpy().astype(np.float32)
+        if flip:
+            f = f[::-1, ::-1]
+        kh = f[0].astype(np.float32)
+        kv = (f[:, 0] / f[0, 0]).astype(np.float32) if f[0, 0] != 0 else np.zeros(4, np.float32)
+        if float(np.abs(f - np.outer(kv, kh)).max()) <= 1e-6 * float(np.abs(f).max()):
+            res = ((C.c_float * 4)(*[float(v) for v in kh]), (C.c_float * 4)(*[float(v) for v in kv]))
+    try:
+        fir._ideas_factors = ((fir._version, flip, fir.data_ptr()), res)
+    except Exception:      # (a tensor subclass without a __dict__)
+        pass
+    return res
+
+
+def _blur_conv_plan(x_shape, w: torch.Tensor, fir: torch.Tensor, pad2):
+    """(Launch of the stride-2 conv on the blurred tensor, blurred height, width), or None when the fused kernel does not apply."""
+    if not BLUR_CONV or MATH != _lib.F32_B3 or tuple(w.shape[2:]) != (3, 3) or tuple(fir.shape) != (4, 4):
+        return None
+    b, ci, h, wd = x_shape
+    p0, p1 = int(pad2[0]), int(pad2[1])
+    hb, wb = h + p0 + p1 - 3, wd + p0 + p1 - 3
+    if hb < 3 or wb < 3 or ci != w.shape[1]:
+        return None
+    L = plan_fwd((b, ci, hb, wb), w, ConvGeom(3, 3, 2, 0, False))
+    if L.OW < BLUR_CONV_MIN_OW or L.OH < 8:
+        return None
+    if not _lib.load().ideas_b3_blur_conv_s2_supported(C.byref(_params(L, 1.0)), h, wd, p0):
+        return None
+    return L, hb, wb
+
+
+def blur_conv_s2_ok(x: torch.Tensor, w: torch.Tensor, fir: torch.Tensor, pad2, want_xb: bool = False) -> bool:
+    if x.dtype != torch.float32 or not x.is_cuda:
+        return False
+    pl = _blur_conv_plan(tuple(x.shape), w, fir, pad2)
+    if pl is None or fir_factors(fir) is None:
+        return False
+    L, hb, wb = pl
+    return (not want_xb) or (hb == 2 * L.OH + 1 and wb == 2 * L.OW + 1)
+
+
+def blur_conv_s2_raw(x, w, fir, pad2, gain: float, bias=None, act: bool = False, act_gain: float = 1.0, alpha: float = 0.2,
+                     resid=None, want_xb: bool = False):
+    """``epilogue(gain * conv2d(upfirdn2d(x, fir, pad=pad2), w, stride=2))`` in one launch -> (y, blurred tensor or None).
+    The caller has checked ``blur_conv_s2_ok``."""
+    x = _nhwc(x)
+    L, hb, wb = _blur_conv_plan(tuple(x.shape), w, fir, pad2)
+    kh, kv = fir_factors(fir)
+    p = _params(L, gain, False, act, alpha, act_gain, 1.0)
+    y = torch.empty((L.B, L.Cout, L.YH, L.YW), device=x.device, dtype=x.dtype, memory_format=CL)
+    xb = torch.empty((L.B, L.Cin, hb, wb), device=x.device, dtype=x.dtype, memory_format=CL) if want_xb else None
+    if resid is not None:
+        resid = _nhwc(resid)
+    rc = _lib.load().ideas_b3_blur_conv_s2(_lib.ptr(y), _lib.ptr(xb), _lib.ptr(x), _lib.ptr(b3_planes(L)), kh, kv,
+                                           _lib.ptr(None if bias is None else bias.contiguous()), _lib.ptr(resid), C.byref(p),
+                                           x.shape[2], x.shape[3], int(pad2[0]), _lib.stream_ptr())
+    _lib.check(rc, "ideas_b3_blur_conv_s2")
+    return y, xb
+
+
+class _DownPair(Function):
+    """The body of a downsampling ResBlock (models.py:185-187 with ConvLayer :68-76, :120-128) as one autograd node:
+
+        y1 = lrelu(gain1 * conv(x, w1) + b1) * ag1                      conv1 (3x3, zero or mirror padding)
+        y2 = lrelu(gain2 * conv_s2(blur(y1), w2) + b2) * ag2            conv2's Blur + stride-2 conv + activation: ONE kernel
+
+    The blurred tensor exists only as the side output the weight gradient of w2 reads (written by the conv kernel, not by a blur
+    pass), and not at all when w2 is frozen (the discriminators in the G phase).  Backward of a plain pass: leaky-ReLU backward of
+    y2 -> input gradient of the stride-2 conv -> blur adjoint + leaky-ReLU mask of y1 + bias gradient in one kernel
+    (ideas_blur_fused) -> conv1's gradients; under create_graph (R1) the same chain composed of the differentiable Functions."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, g1: ConvGeom, gain1: float, slope1: float, ag1: float, fir, pad2, gain2: float,
+                slope2: float, ag2: float):
+        from .upfirdn2d import blur_geometry
+        x = _nhwc(x)
+        y1 = conv_fwd_raw(x, w1, g1, gain1, bias=b1.contiguous(), act=True, act_gain=ag1, alpha=slope1)
+        need_xb = ctx.needs_input_grad[3]
+        y2, yb = blur_conv_s2_raw(y1, w2, fir, pad2, gain2, bias=b2, act=True, act_gain=ag2, alpha=slope2, want_xb=need_xb)
+        pad4, out_hw, g_pad = blur_geometry((y1.shape[2], y1.shape[3]), fir, pad2)
+        ctx.g1, ctx.gain1, ctx.slope1, ctx.ag1 = g1, gain1, slope1, ag1
+        ctx.gain2, ctx.slope2, ctx.ag2 = gain2, slope2, ag2
+        ctx.pad4, ctx.g_pad, ctx.out_hw = pad4, g_pad, out_hw
+        ctx.b1_ref, ctx.b2_ref = b1, b2
+        ctx.save_for_backward(x, w1, y1, w2, y2, fir, yb)
+        return y2
+
+    @staticmethod
+    def backward(ctx, gy2):
+        from .fused_act import FusedLeakyReLUFunctionBackward, bias_act_raw, bias_sink
+        from .upfirdn2d import BLUR_ACT_BWD, UpFirDn2dBackward, blur_fused_ok, blur_fused_raw, upfirdn2d_raw
+        x, w1, y1, w2, y2, fir, yb = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g2 = ConvGeom(3, 3, 2, 0, False)
+        gb1 = gb2 = None
+        tgt2 = bias_sink(ctx.b2_ref) if need[4] else None
+        if tgt2 is not None:
+            g_pre2, _ = bias_act_raw(gy2, None, y2, 1, ctx.slope2, ctx.ag2, bias_grad_into=tgt2)
+        else:
+            g_pre2, gb2 = FusedLeakyReLUFunctionBackward.apply(gy2, y2, ctx.slope2, ctx.ag2, True)
+        gw2 = None
+        if need[3]:
+            if yb is None:      # (cannot happen: w2 required a gradient in the forward, so the side output was written)
+                yb = upfirdn2d_raw(y1, fir, (1, 1), (1, 1), ctx.pad4, ctx.out_hw, flip=True)
+            gw2 = _wgrad(w2, g_pre2, yb, g2, ctx.gain2)
+        gyb = _ConvDgrad.apply(g_pre2, w2, g2, ctx.gain2, ctx.out_hw)
+        if torch.is_grad_enabled() or not blur_fused_ok(y1, fir):
+            g1 = UpFirDn2dBackward.apply(gyb, fir, (1, 1), (1, 1), ctx.pad4, ctx.g_pad, tuple(y1.shape), ctx.out_hw)
+            g_pre1, gb1 = FusedLeakyReLUFunctionBackward.apply(g1, y1, ctx.slope1, ctx.ag1, True)
+        else:
+            tgt1 = bias_sink(ctx.b1_ref) if need[2] else None
+            if tgt1 is None:
+                gb1 = torch.zeros(y1.shape[1], device=y1.device, dtype=torch.float32)
+            g_pre1 = blur_fused_raw(_nhwc(gyb), fir, ctx.g_pad, (y1.shape[2], y1.shape[3]), False, BLUR_ACT_BWD, ref=y1,
+                                    bias_grad=tgt1 if tgt1 is not None else gb1, alpha=ctx.slope1, scale=ctx.ag1)
+            if tgt1 is not None:
+                gb1 = None
+        gx = gw1 = None
+        if need[0]:
+            gx = _ConvDgrad.apply(g_pre1, w1, ctx.g1, ctx.gain1, (x.shape[2], x.shape[3]))
+        if need[1]:
+            gw1 = _wgrad(w1, g_pre1, x, ctx.g1, ctx.gain1)
+        return (gx, gw1, (gb1 if need[2] else None), gw2, (gb2 if (need[4] and tgt2 is None) else None),
+                None, None, None, None, None, None, None, None, None)
+
+
+def down_pair_ok(input: torch.Tensor, w1, w2, fir, pad2, padding1: int = 1) -> bool:
+    """Shapes / precision ``down_pair`` covers: f32 activations (the bf16 path keeps its own kernels), the split-bf16 contraction,
+    a separable 4x4 FIR, >= 8 x 16 output pixels per image, Cin % 16 == 0; with a weight gradient pending also the blurred size
+    2 OH + 1 (every blurred pixel is then written by the conv kernel's side output)."""
+    from ..precision import activation_dtype
+    if not input.is_cuda or activation_dtype() != torch.float32 or input.dim() != 4:
+        return False
+    g1 = ConvGeom(w1.shape[2], w1.shape[3], 1, padding1, False)
+    oh, ow = g1.out_size(input.shape[2], input.shape[3])
+    pl = _blur_conv_plan((input.shape[0], w1.shape[0], oh, ow), w2, fir, pad2)
+    if pl is None or fir_factors(fir) is None:
+        return False
+    if torch.is_grad_enabled() and w2.requires_grad and not (pl[1] == 2 * pl[0].OH + 1 and pl[2] == 2 * pl[0].OW + 1):
+        return False
+    return True
+
+
+def down_pair(input: torch.Tensor, w1, b1, w2, b2, fir, pad2, padding1: int = 1, reflect1: bool = False, gain1: float = 1.0,
+              gain2: float = 1.0, negative_slope: float = 0.2, scale1: float = 2 ** 0.5, scale2: float = 2 ** 0.5,
+              resid: Optional[torch.Tensor] = None):
+    """``act2(conv_s2(blur(act1(conv(input, w1)), fir, pad2), w2))``, the body of a downsampling ResBlock, with the Blur inside the
+    stride-2 conv's kernel; the caller has checked ``down_pair_ok``.  ``resid`` (no-grad passes only): added in the last epilogue."""
+    _lib.require_cuda(input, w1, b1, w2, b2, fir)
+    input = to_act(input)
+    g1 = ConvGeom(w1.shape[2], w1.shape[3], 1, padding1, reflect1)
+    grad = torch.is_grad_enabled() and (input.requires_grad or w1.requires_grad or b1.requires_grad or w2.requires_grad or b2.requires_grad)
+    if not grad:
+        y1 = conv_fwd_raw(_nhwc(input), w1, g1, float(gain1), bias=b1.contiguous(), act=True, act_gain=float(scale1),
+                          alpha=float(negative_slope))
+        return blur_conv_s2_raw(y1, w2, fir, pad2, float(gain2), bias=b2, act=True, act_gain=float(scale2),
+                                alpha=float(negative_slope), resid=None if resid is None else to_act(resid))[0]
+    if resid is not None:
+        raise RuntimeError("down_pair(resid=...) is the no-grad fast path")
+    return _DownPair.apply(input, w1, b1, w2, b2, g1, float(gain1), float(negative_slope), float(scale1), fir,
+                           (int(pad2[0]), int(pad2[1])), float(gain2), float(negative_slope), float(scale2))
 
 
 def conv2d_bias_act(input: torch.Tensor, weight: torch.Tensor, act_bias: torch.Tensor, stride: int = 1, padding: int = 0,

@@ -100,7 +100,8 @@ PREFILL = _os.environ.get("IDEAS_PREFILL", "1") != "0"
 STYLE_CACHE = _os.environ.get("IDEAS_STYLE_CACHE", "1") != "0"
 _RECORDED = {}      # cache key -> (prep, weakref of the base parameter, its data_ptr when recorded)
 _PREP_STATE = {}    # tuple of cache keys -> per-op launch state (device table, blocks, persistent outputs)
-_KEYS_OF = {}       # span set (None = everything) -> the sorted tuple of recorded keys inside it
+_KEYS_OF = {}       # (span set (None = everything), precision) -> the sorted tuple of recorded keys inside it
+_OUT_BUF = {}       # cache key -> its persistent destination buffer, shared by every span selection that contains the key
 
 
 def _prep_state(keys):
@@ -121,7 +122,9 @@ def _prep_state(keys):
             (_, numel, a, sv, unit, src, work), ref, _p0 = _RECORDED[k]
             base = ref()
             dev = base.device
-            out = torch.empty(numel, device=dev, dtype=torch.bfloat16)
+            out = _OUT_BUF.get(k)
+            if out is None or out.numel() != numel or out.device != dev:
+                out = _OUT_BUF[k] = torch.empty(numel, device=dev, dtype=torch.bfloat16)
             nb = int(min(work // 256 + 1, 2048))
             d = descs[i]
             d.dst, d.w = out.data_ptr(), src
@@ -148,21 +151,28 @@ def _prefill(spans=None) -> None:
     if dead:
         for k in dead:
             del _RECORDED[k]
+            _OUT_BUF.pop(k, None)
         _PREP_STATE.clear()
         _KEYS_OF.clear()
+    # Forms of the other arithmetic mode are not remade: a process that ran f32 iterations and then switches to bf16 activations
+    # (bench.py --also-bf16) would otherwise split every weight into b3 planes after each optimiser step for nothing (the few
+    # tiny layers a mode still computes with the other mode's kernels miss the cache and are remade one by one, as before).
+    from ..precision import activation_dtype
+    bf = activation_dtype() == torch.bfloat16
+    live = lambda k: str(k[3][0]).startswith("bf16") == bf
     # (the selection + sort is ~1.5 ms of host time for ~400 entries, three times per iteration, at points where the GPU queue is
     #  empty -- right behind an optimiser step; memoised per span set until _RECORDED changes)
-    sel = None if spans is None else tuple((a, b) for a, b in spans)
+    sel = (None if spans is None else tuple((a, b) for a, b in spans), bf)
     keys = _KEYS_OF.get(sel)
     if keys is None:
         if spans is None:
-            keys = tuple(sorted(_RECORDED, key=lambda k: (k[0], repr(k[1:]))))
+            keys = tuple(sorted((k for k in _RECORDED if live(k)), key=lambda k: (k[0], repr(k[1:]))))
         else:
             starts = [m[0] for m in spans]
             keys = []
             for k in _RECORDED:
                 i = bisect.bisect_right(starts, k[0]) - 1
-                if i >= 0 and k[0] < spans[i][1]:
+                if i >= 0 and k[0] < spans[i][1] and live(k):
                     keys.append(k)
             keys = tuple(sorted(keys, key=lambda k: (k[0], repr(k[1:]))))
         _KEYS_OF[sel] = keys
@@ -236,7 +246,12 @@ def cached(w: torch.Tensor, key, make, prep=None):
     return v
 
 
-def cached_on(w: torch.Tensor, key, t: torch.Tensor, make):
+# Byte budget of the per-sample bf16 weight packs memoised by cached_on(..., budget=True): tens to hundreds of MB each at B = 32
+STYLE_BUDGET_MB = int(_os.environ.get("IDEAS_STYLE_BUDGET_MB", "1536"))
+_BUDGETED = {}      # cache key -> bytes, in insertion order
+
+
+def cached_on(w: torch.Tensor, key, t: torch.Tensor, make, budget: bool = False):
     """`make()` memoised on a parameter (as ``cached``) AND on the identity of a second tensor `t` (address + version counter) --
     the per-sample styles of a modulated conv: G is applied to the same texture code two or three times per iteration (train.py:58,
     :68, :145-160), and everything derived from (weights, styles) -- the styles themselves, the demodulation factors, the bf16
@@ -252,6 +267,16 @@ def cached_on(w: torch.Tensor, key, t: torch.Tensor, make):
     if v is None:
         v = (t, make())
         _CACHE[k] = v
+        if budget and torch.is_tensor(v[1]):
+            for dead in [q for q in _BUDGETED if q not in _CACHE]:      # (dropped by cache_clear / a new iteration)
+                del _BUDGETED[dead]
+            _BUDGETED[k] = v[1].numel() * v[1].element_size()
+            total = sum(_BUDGETED.values())
+            for old in list(_BUDGETED):
+                if total <= STYLE_BUDGET_MB << 20 or old == k:
+                    break
+                total -= _BUDGETED.pop(old)
+                _CACHE.pop(old, None)
     return v[1]
 
 

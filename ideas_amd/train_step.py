@@ -153,21 +153,51 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
     """``_train_iteration`` with the derived-weight cache (op/conv_plan.py) switched on for its duration."""
     conv_plan.cache_begin()
     scratch.begin(X.device)          # one pre-zeroed arena (one memset) for the small reduction outputs of the backward passes
+    pending: list = []               # deferred gradient exchanges not yet completed (see _Deferred)
     try:
-        return _train_iteration(trainer, args, X, iter_idx, draws, reducer, hook)
+        return _train_iteration(trainer, args, X, iter_idx, draws, reducer, hook, pending)
     finally:
+        # an exception between a deferred exchange's start and its finish() must not leave the all-reduce un-waited while the next
+        # iteration's zero_grad writes the same flat buffer
+        for d in pending:
+            d.abandon()
         scratch.end()
         conv_plan.cache_end()
 
 
+class DeferredStepError(RuntimeError):
+    pass
+
+
+_D_PENDING = [False]      # the D group's optimiser step is deferred: no discriminator may run (it would read pre-step weights)
+
+
+def _guard_discriminators(trainer) -> None:
+    """Once per trainer: forward pre-hooks on the discriminators that refuse to run while their optimiser step is deferred."""
+    if trainer.get("_d_guard"):
+        return
+
+    def pre(module, inputs):
+        if _D_PENDING[0]:
+            raise DeferredStepError(f"{type(module).__name__} called while the D group's optimiser step is deferred: it would run on "
+                                    "pre-step weights (train_step._Deferred: finish() must come first)")
+    for n in D_SIDE:
+        if isinstance(trainer.get(n), torch.nn.Module):
+            trainer[n].register_forward_pre_hook(pre)
+    trainer["_d_guard"] = True
+
+
 def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optional[StepDraws] = None,
-                     reducer=None, hook: Optional[Callable] = None) -> Dict[str, torch.Tensor]:
+                     reducer=None, hook: Optional[Callable] = None, pending_list: Optional[list] = None) -> Dict[str, torch.Tensor]:
     """Run one iteration in place on ``trainer``; returns the loss tensors (no host sync).
 
     ``reducer(group_name, params)`` is called after each backward (``'d'``, ``'r1'``, ``'g'``, ``'ex'``) to
     average gradients across ranks.  ``hook(tag, params)`` is a test hook called at the same points, just
     before the optimiser step."""
     T = trainer
+    _guard_discriminators(T)
+    if pending_list is None:
+        pending_list = []
     if draws is None:
         draws = draw_step(args, X.shape[0], X.shape[-1], X.device)
     losses: Dict[str, torch.Tensor] = {}
@@ -189,15 +219,39 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         def __init__(self, tag, params, opt, ema=True, refill=True):
             self.tag, self.params, self.opt, self.ema, self.refill = tag, params, opt, ema, refill
             self.pending = reducer.start(tag, params) if (reducer is not None and hasattr(reducer, "start")) else None
+            self.done = False
+            pending_list.append(self)
+            if tag == "d":
+                _D_PENDING[0] = True      # nothing may run a discriminator until finish() (checked by their forward pre-hooks)
+
+        def _release(self):
+            self.done = True
+            if self.tag == "d":
+                _D_PENDING[0] = False
+            if self in pending_list:
+                pending_list.remove(self)
 
         def finish(self):
-            if self.pending is not None:
-                self.pending.wait()
-            elif reducer is not None:
-                reducer(self.tag, self.params)
+            try:
+                if self.pending is not None:
+                    self.pending.wait()
+                elif reducer is not None:
+                    reducer(self.tag, self.params)
+            finally:
+                self._release()
             if hook is not None:
                 hook(self.tag, self.params)
             _step(self.opt, ema=self.ema, refill=self.refill)
+
+        def abandon(self):
+            """Error path: complete the exchange (the flat buffer must be quiescent), skip the optimiser step."""
+            if self.done:
+                return
+            try:
+                if self.pending is not None:
+                    self.pending.wait()
+            finally:
+                self._release()
 
     # ------------------------------------------------------------------ D phase (train.py:48-102)
     share = bool(getattr(args, "share_forward", True))

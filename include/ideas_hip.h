@@ -272,6 +272,23 @@ int ideas_wino_wgrad_fold(float* gw, float* gu, int Cout, int Cin, int64_t so, i
 int ideas_conv_igemm_multi(int n, void* y, const void* x, const void* const* wmat, const float* in_scale, const float* out_scale,
                            const ideas_conv_params* params, int dtype, void* stream);
 
+/* Blur -> 3x3 / stride-2 convolution of a downsampling ConvLayer in ONE kernel (csrc/conv_b3_s2fir.hip, dtype IDEAS_F32_B3 only):
+ * replaces upfirdn2d_op(x, kernel, pad) followed by F.conv2d(stride=2) (models.py:68-76 -> stylegan2/model.py:88-91, 115-121) without
+ * writing the blurred tensor to HBM: a block builds the blurred pixels under its 8 x 16 output patch in LDS (the separable 4-tap FIR
+ * in f32, then the exact 3-way bf16 split) and contracts the nine stride-2 taps from that image.
+ *   p        the stride-2 convolution on the BLURRED tensor [B, IH, IW, Cin]: TY = TX = 3, sy = sx = 2, no padding, dense output
+ *            (YH = OH = (IH - 3) / 2 + 1); epilogue fields (gain, act, alpha, act_gain, resid_gain) as ideas_conv_igemm;
+ *   x        the RAW input [B, xh, xw, Cin] f32 NHWC; IH = xh + pad0 + pad1 - 3 with 0 <= pad0, pad1 <= 3 (the Blur's pads);
+ *   fir_h/v  HOST pointers to the 4 + 4 factors of the flipped, gain-scaled FIR: xb[i,j] = sum_a fir_v[a] * (sum_b fir_h[b] *
+ *            x[i + a - pad0, j + b - pad0]) -- evaluated in exactly that order with fused multiply-adds, as the stand-alone blur does;
+ *   wplanes  the planes of ideas_b3_split_weights for the [Cout][3*3*Cin] matrix; bias / resid optional (float[Cout] / y's shape);
+ *   xb_out   optional [B, IH, IW, Cin] f32: the blurred tensor as a side output (the operand of the layer's weight gradient); needs
+ *            IH == 2*OH + 1 and IW == 2*OW + 1 (every blurred pixel lies under some output pixel's taps), else IDEAS_E_UNSUPPORTED.
+ * ideas_b3_blur_conv_s2_supported: 1 if the geometry is covered (Cin % 16 == 0, Cout % 4 == 0, tensors < 4 GiB). */
+int ideas_b3_blur_conv_s2_supported(const ideas_conv_params* p, int xh, int xw, int pad0);
+int ideas_b3_blur_conv_s2(void* y, void* xb_out, const void* x, const void* wplanes, const float* fir_h, const float* fir_v,
+                          const float* bias, const void* resid, const ideas_conv_params* p, int xh, int xw, int pad0, void* stream);
+
 /* Generic direct convolution (VALU) with the same parameterisation and epilogue; any Cin/Cout. Used for the
  * handful of tiny-K layers (RGB / N-channel inputs) where the MFMA tile would be empty. */
 /* (dtype IDEAS_F32, or IDEAS_BF16: bf16 x / y / resid / gy with f32 weights, scales, bias and weight gradient) */

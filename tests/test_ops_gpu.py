@@ -1351,3 +1351,177 @@ def test_conv_bias_gradient_small_channel_count(ops, transposed):
     (r1,) = torch.autograd.grad(y2.square().sum(), x, create_graph=True)
     (rb2,) = torch.autograd.grad(r1.square().sum(), b)
     assert rel_err(gb2, rb2) < GTOL
+
+
+# ------------------------------------------------------------------------------------- Blur -> 3x3 / stride-2 conv in one kernel
+# (B, Cin, Cout, H, W, pad, with_bias_act, with_resid): raw sizes; blurred = H + pad0 + pad1 - 3.  Odd blurred sizes 257 / 129 / 65 / 33 / 17
+# (the discriminator's and encoder's stages), even ones (odd raw inputs: the last blurred row / column is unused), partial patches in
+# both directions, the three channel tiles (Cout <= 64, <= 128, > 128 incl. two N tiles and a ragged last one), pad (1, 1).
+BLUR_CONV_CASES = [
+    (1, 16, 128, 256, 256, (2, 2), True, False), (2, 32, 64, 128, 128, (2, 2), True, False), (2, 64, 256, 64, 64, (2, 2), True, True),
+    (3, 128, 128, 32, 32, (2, 2), True, False), (2, 512, 512, 32, 32, (2, 2), True, False), (2, 16, 320, 16, 32, (2, 2), False, False),
+    (2, 32, 96, 33, 47, (2, 2), True, True), (1, 48, 36, 40, 71, (2, 2), False, False), (2, 16, 132, 37, 34, (1, 1), True, False),
+    (1, 16, 64, 19, 35, (2, 1), False, True),
+]
+
+
+def _blur_conv_ref(x, w, fir2d, pad, scale, bias, act, resid):
+    xb = O.upfirdn2d(x, fir2d, pad=pad)
+    y = F.conv2d(xb, w * scale, stride=2)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    if act:
+        y = F.leaky_relu(y, 0.2) * math.sqrt(2)
+    if resid is not None:
+        y = (y + resid) * 0.5
+    return y, xb
+
+
+@pytest.mark.parametrize("case", BLUR_CONV_CASES)
+def test_blur_conv_s2_vs_oracle(case):
+    """ideas_b3_blur_conv_s2 (csrc/conv_b3_s2fir.hip) against upfirdn2d -> conv2d(stride 2) in f64 (stylegan2/model.py:88-91, 115-121),
+    its blurred side output against the stand-alone blur kernel (same taps, same FMA order: bitwise), and against the two-kernel path."""
+    from ideas_amd.model import make_kernel
+    from ideas_amd.op import conv as convmod
+    from ideas_amd.op.upfirdn2d import upfirdn2d_raw
+    B, ci, co, H, W, pad, bact, with_resid = case
+    torch.manual_seed(sum(case[:5]))
+    fir = make_kernel((1, 3, 3, 1))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    w = torch.randn(co, ci, 3, 3, dtype=torch.float64)
+    bias = torch.randn(co, dtype=torch.float64) * 0.3 if bact else None
+    scale = 1 / math.sqrt(ci * 9)
+    hb, wb = H + pad[0] + pad[1] - 3, W + pad[0] + pad[1] - 3
+    oh, ow = (hb - 3) // 2 + 1, (wb - 3) // 2 + 1
+    resid = torch.randn(B, co, oh, ow, dtype=torch.float64) if with_resid else None
+    y, xb = _blur_conv_ref(x, w, fir.double(), pad, scale, bias, bact, resid)
+    xd, wd, fd = dev(x.float(), True), dev(w.float(), True), fir.cuda()
+    assert convmod.blur_conv_s2_ok(xd, wd, fd, pad), case
+    want_xb = convmod.blur_conv_s2_ok(xd, wd, fd, pad, want_xb=True)
+    assert want_xb == (hb == 2 * oh + 1 and wb == 2 * ow + 1)
+    p = convmod._params(convmod._blur_conv_plan(tuple(xd.shape), wd, fd, pad)[0], scale, False, bact, 0.2, math.sqrt(2), 0.5 if with_resid else 1.0)
+    # (the raw launcher always passes resid_gain 1; the C ABI takes any) -> go through the C ABI directly for the resid case
+    if with_resid:
+        from ideas_amd import _lib
+        import ctypes as C
+        L = convmod._blur_conv_plan(tuple(xd.shape), wd, fd, pad)[0]
+        kh, kv = convmod.fir_factors(fd)
+        yd = torch.empty((B, co, oh, ow), device="cuda", memory_format=CL)
+        rd = dev(resid.float(), True)
+        rc = _lib.load().ideas_b3_blur_conv_s2(_lib.ptr(yd), None, _lib.ptr(xd), _lib.ptr(convmod.b3_planes(L)), kh, kv,
+                                               _lib.ptr(None if bias is None else bias.float().cuda()), _lib.ptr(rd), C.byref(p), H, W, pad[0],
+                                               _lib.stream_ptr())
+        _lib.check(rc, "ideas_b3_blur_conv_s2")
+        xbd = None
+    else:
+        yd, xbd = convmod.blur_conv_s2_raw(xd, wd, fd, pad, scale, bias=None if bias is None else bias.float().cuda(), act=bact,
+                                           act_gain=math.sqrt(2), want_xb=want_xb)
+    assert tuple(yd.shape) == tuple(y.shape)
+    assert rel_err(yd, y) < TOL, ("y", case, rel_err(yd, y))
+    if xbd is not None:
+        assert rel_err(xbd, xb) < TOL
+        blur = upfirdn2d_raw(xd, fd, (1, 1), (1, 1), (pad[0], pad[1], pad[0], pad[1]), (hb, wb), flip=True)
+        assert torch.equal(xbd, blur), float((xbd - blur).abs().max())
+    # the unfused chain on the same device: same error class
+    from ideas_amd.op import conv2d, upfirdn2d
+    y2 = conv2d(upfirdn2d(xd, fd, pad=pad), wd, None, stride=2, gain=scale)
+    if not bact and not with_resid:
+        assert rel_err(yd, y2) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 64, "zero"), (1, 16, 128, 32, 48, "reflect"), (2, 64, 256, 32, 32, "zero"), (1, 16, 32, 16, 32, "zero")])
+@pytest.mark.parametrize("freeze2", [False, True])
+def test_down_pair_gradients_vs_oracle(case, freeze2):
+    """op.conv.down_pair (conv1 -> [Blur -> stride-2 conv2] of a downsampling ResBlock body as one autograd node, models.py:185-187):
+    forward and every gradient against the f64 composite; with conv2 frozen (the G phase's discriminator passes) no blurred tensor
+    is written at all."""
+    from ideas_amd.model import make_kernel
+    from ideas_amd.op import conv as convmod
+    B, ci, co, H, W, padding = case
+    torch.manual_seed(sum(case[:5]) + int(freeze2))
+    fir = make_kernel((1, 3, 3, 1))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64).requires_grad_(True)
+    w1 = torch.randn(co, ci, 3, 3, dtype=torch.float64).requires_grad_(True)
+    w2 = torch.randn(co, co, 3, 3, dtype=torch.float64).requires_grad_(True)
+    b1 = (torch.randn(co, dtype=torch.float64) * 0.3).requires_grad_(True)
+    b2 = (torch.randn(co, dtype=torch.float64) * 0.3).requires_grad_(True)
+    s1, s2 = 1 / math.sqrt(ci * 9), 1 / math.sqrt(co * 9)
+    xin = F.pad(x, [1] * 4, mode="reflect") if padding == "reflect" else x
+    y1 = F.leaky_relu(F.conv2d(xin, w1 * s1, padding=0 if padding == "reflect" else 1) + b1.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    y2 = F.leaky_relu(F.conv2d(O.upfirdn2d(y1, fir.double(), pad=(2, 2)), w2 * s2, stride=2) + b2.view(1, -1, 1, 1), 0.2) * (math.sqrt(2) * 0.7)
+    gy = torch.randn_like(y2)
+    ref = torch.autograd.grad(y2, (x, w1, b1, w2, b2), gy)
+    t = lambda v: dev(v.float(), True).requires_grad_(True)
+    xd, w1d, w2d, b1d, b2d = t(x), t(w1), t(w2), t(b1), t(b2)
+    if freeze2:
+        w2d.requires_grad_(False); b2d.requires_grad_(False)
+    fd = fir.cuda()
+    assert convmod.down_pair_ok(xd, w1d, w2d, fd, (2, 2), 1)
+    yd = convmod.down_pair(xd, w1d, b1d, w2d, b2d, fd, (2, 2), padding1=1, reflect1=padding == "reflect", gain1=s1, gain2=s2,
+                           scale2=math.sqrt(2) * 0.7)
+    assert rel_err(yd, y2) < TOL, rel_err(yd, y2)
+    ins = (xd, w1d, b1d) + (() if freeze2 else (w2d, b2d))
+    got = torch.autograd.grad(yd, ins, dev(gy.float(), True))
+    for name, a, b in zip(("x", "w1", "b1", "w2", "b2"), got, ref):
+        assert rel_err(a, b) < GTOL, (name, case, rel_err(a, b))
+
+
+def test_down_pair_double_backward_r1():
+    """R1 through the fused pair (utils.py:112-118): d/dw of |d(sum y)/dx|^2 composes the differentiable Functions in the backward."""
+    from ideas_amd.model import make_kernel
+    from ideas_amd.op import conv as convmod
+    torch.manual_seed(11)
+    B, ci, co, H = 2, 16, 32, 32
+    fir = make_kernel((1, 3, 3, 1))
+    x = torch.randn(B, ci, H, H, dtype=torch.float64).requires_grad_(True)
+    w1 = torch.randn(co, ci, 3, 3, dtype=torch.float64).requires_grad_(True)
+    w2 = torch.randn(co, co, 3, 3, dtype=torch.float64).requires_grad_(True)
+    b1 = (torch.randn(co, dtype=torch.float64) * 0.3).requires_grad_(True)
+    b2 = (torch.randn(co, dtype=torch.float64) * 0.3).requires_grad_(True)
+    s1, s2 = 1 / math.sqrt(ci * 9), 1 / math.sqrt(co * 9)
+
+    def ref_f():
+        y1 = F.leaky_relu(F.conv2d(x, w1 * s1, padding=1) + b1.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+        return F.leaky_relu(F.conv2d(O.upfirdn2d(y1, fir.double(), pad=(2, 2)), w2 * s2, stride=2) + b2.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    y = ref_f()
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    pen = gx.pow(2).sum()
+    ref = torch.autograd.grad(pen, (w1, b1, w2, b2), allow_unused=True)
+    t = lambda v: dev(v.float(), True).requires_grad_(True)
+    xd, w1d, w2d, b1d, b2d = t(x), t(w1), t(w2), t(b1), t(b2)
+    yd = convmod.down_pair(xd, w1d, b1d, w2d, b2d, fir.cuda(), (2, 2), padding1=1, gain1=s1, gain2=s2)
+    (gxd,) = torch.autograd.grad(yd.sum(), xd, create_graph=True)
+    assert rel_err(gxd, gx) < GTOL
+    pend = gxd.pow(2).sum()
+    got = torch.autograd.grad(pend, (w1d, b1d, w2d, b2d), allow_unused=True)
+    assert abs(float(pend) - float(pen)) <= 1e-4 * abs(float(pen))
+    for name, a, b in zip(("w1", "b1", "w2", "b2"), got, ref):
+        if b is None:
+            assert a is None or float(a.abs().max()) == 0.0, name
+        else:
+            assert rel_err(a, b) < 2e-4, (name, rel_err(a, b))
+
+
+def test_downsampling_resblock_fused_blur_conv_equals_layerwise_path(monkeypatch):
+    """ResBlock.forward with the Blur inside conv2's kernel vs the layer-by-layer path (IDEAS_BLUR_CONV=0) on the same weights: outputs
+    and parameter / input gradients agree to the kernels' rounding, under autograd and under no_grad (residual in the epilogue)."""
+    import ideas_amd.models as M
+    torch.manual_seed(5)
+    blk = M.ResBlock(32, 64, downsample=True).cuda()
+    for n_, p_ in blk.named_parameters():
+        if n_.endswith("bias"):
+            p_.data.normal_(0, 0.2)
+    x = dev(torch.randn(2, 32, 64, 64), True).requires_grad_(True)
+    gy = dev(torch.randn(2, 64, 32, 32), True)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(M, "FUSE_BLUR_CONV", fused)
+        y = blk(x)
+        g = torch.autograd.grad(y, [x] + list(blk.parameters()), gy)
+        with torch.no_grad():
+            yn = blk(x)
+        res[fused] = (y, g, yn)
+    assert rel_err(res[True][0], res[False][0]) < 3e-6 and rel_err(res[True][2], res[False][2]) < 3e-6
+    assert rel_err(res[True][2], res[True][0]) < 3e-6
+    for a, b in zip(res[True][1], res[False][1]):
+        assert rel_err(a, b) < 2e-5, rel_err(a, b)

@@ -19,7 +19,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list); dur = []
 for f in sorted(glob.glob("$R/$OUT/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("conv_b3_kernel", "conv_b3_wino_kernel", "conv_igemm_kernel", "conv3x3_wino", "wgrad_kernel")):
+        if any(k in r["Kernel_Name"] for k in ("conv_b3_kernel", "conv_b3_wino_kernel", "conv_igemm_kernel", "conv3x3_wino", "wgrad_kernel", "conv_b3_s2fir_kernel")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 print("kernel ms (profiled):", sum(dur) / max(len(dur), 1))
