@@ -848,6 +848,7 @@ def test_batched_weight_refill_is_bitwise_the_single_launches():
                     if Ld.Cin % 32 == 0:
                         out.append(CV.bf16_pack(Ld))
         return out
+    from ideas_amd.precision import activations
     conv_plan.cache_begin()
     try:
         first = forms()                                   # misses: made one by one and remembered
@@ -856,18 +857,33 @@ def test_batched_weight_refill_is_bitwise_the_single_launches():
         with torch.no_grad():
             for w in ws:
                 w.mul_(1.5).add_(0.01)
-        conv_plan.cache_clear(ws)                         # -> batched refill of everything remembered for these parameters
-        hits_before = len(conv_plan._CACHE)
-        assert hits_before >= n_rec
-        batched = [t.clone() for t in forms()]            # cache hits (the batched results)
-        assert len(conv_plan._CACHE) <= hits_before + 2
+        # The refill remakes the forms of the ACTIVE arithmetic mode only (a process that switches to bf16 activations must
+        # not keep splitting every weight into b3 planes): the f32 pass refills the split / Winograd planes, the bf16 pass the packs.
+        batched = {}
+        for dt in (torch.float32, torch.bfloat16):
+            with activations(dt):
+                conv_plan.cache_clear(ws)                 # -> batched refill of what is remembered for these parameters in this mode
+                want = [k for k in conv_plan._RECORDED if str(k[3][0]).startswith("bf16") == (dt == torch.bfloat16)]
+                assert want and all(k in conv_plan._CACHE for k in want)
+                other = [k for k in conv_plan._RECORDED if k not in want]
+                assert other and not any(k in conv_plan._CACHE for k in other)
+                for k in want:
+                    batched[k] = conv_plan._CACHE[k].clone()
+        assert len(batched) == n_rec
+        again = forms()                                   # hits for the active mode's forms, single launches for the others
     finally:
         conv_plan.cache_end()
     single = forms()                                      # cache off: the single-tensor launches
-    assert len(single) == len(batched) == len(first)
-    for a, b, c in zip(batched, single, first):
+    assert len(single) == len(again) == len(first)
+    for a, b, c in zip(again, single, first):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
         assert not torch.equal(a.view(torch.int16), c.view(torch.int16))     # (the update did change them)
+    # every batched result is bitwise one of the single-tensor launches' results
+    singles = {}
+    for t in single:
+        singles.setdefault(t.numel(), []).append(t.view(torch.int16))
+    for k, v in batched.items():
+        assert any(torch.equal(v.view(torch.int16), t) for t in singles.get(v.numel(), [])), k[3]
     conv_plan._RECORDED.clear()                           # (what this test remembered must not leak into later tests' refills)
     conv_plan._PREP_STATE.clear()
     conv_plan._KEYS_OF.clear()
