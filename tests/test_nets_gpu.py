@@ -560,8 +560,10 @@ def _full_width_grad_case(name):
     return net, fn, cfg, xs, gen
 
 
-def _full_width_grad_errors(name, prepare=None):
-    """{tensor label: (max-abs gpu, max-abs f32 oracle, l2 gpu, l2 f32 oracle)}, all relative, truth = the oracle in f64."""
+def _full_width_grad_errors(name, prepare=None, act_dtype=None, fwd_tol=2e-5):
+    """{tensor label: (max-abs gpu, max-abs f32 oracle, l2 gpu, l2 f32 oracle)}, all relative, truth = the oracle in f64.
+    ``act_dtype`` (torch.bfloat16): run the GPU networks in that activation precision (ideas_amd.precision); the per-tensor cosines
+    against the f64 truth are left in ``_full_width_grad_errors.cosine``."""
     net, fn, cfg, xs, gen = _full_width_grad_case(name)
     if prepare is not None:
         prepare(net)
@@ -585,16 +587,19 @@ def _full_width_grad_errors(name, prepare=None):
     del ys32, in32, P32
     net.cuda()
     ind = [(x.cuda().contiguous(memory_format=CL) if x.dim() == 4 else x.cuda()).requires_grad_(True) for x in xs]
-    if name == "Dco":
-        yd = (net(ind[0], ind[1], ref_batch=2)[0],)
-    else:
-        yd = net(*ind)
-        yd = yd if isinstance(yd, tuple) else (yd,)
-    for i, (a, b) in enumerate(zip(yd, ys64)):
-        assert rel_err(a, b) < 2e-5, (name, "out", i, rel_err(a, b))
-    gd = torch.autograd.grad(sum((y * w.cuda()).sum() for y, w in zip(yd, ws)), ind + list(net.parameters()), allow_unused=True)
+    from ideas_amd import precision
+    with precision.activations(act_dtype if act_dtype is not None else precision.activation_dtype()):
+        if name == "Dco":
+            yd = (net(ind[0], ind[1], ref_batch=2)[0],)
+        else:
+            yd = net(*ind)
+            yd = yd if isinstance(yd, tuple) else (yd,)
+        for i, (a, b) in enumerate(zip(yd, ys64)):
+            assert rel_err(a, b) < fwd_tol, (name, "out", i, rel_err(a, b))
+        gd = torch.autograd.grad(sum((y.float() * w.cuda()).sum() for y, w in zip(yd, ws)), ind + list(net.parameters()), allow_unused=True)
     labels = [f"in{i}" for i in range(len(xs))] + keys
     res = {}
+    _full_width_grad_errors.cosine = cosine = {}
     for lab, a, b32, b64 in zip(labels, gd, g32, g64):
         if b64 is None:
             assert a is None or float(a.abs().max()) == 0.0, lab
@@ -603,6 +608,7 @@ def _full_width_grad_errors(name, prepare=None):
         if scale == 0.0:
             continue
         d_gpu, d_f32 = a.detach().double().cpu() - b64, b32.double() - b64
+        cosine[lab] = float(torch.nn.functional.cosine_similarity(a.detach().double().cpu().flatten(), b64.flatten(), dim=0))
         res[lab] = (float(d_gpu.abs().max()) / scale, float(d_f32.abs().max()) / scale,
                     float(d_gpu.norm() / b64.norm()), float(d_f32.norm() / b64.norm()))
     return res

@@ -1541,3 +1541,51 @@ def test_downsampling_resblock_fused_blur_conv_equals_layerwise_path(monkeypatch
     assert rel_err(res[True][2], res[True][0]) < 3e-6
     for a, b in zip(res[True][1], res[False][1]):
         assert rel_err(a, b) < 2e-5, rel_err(a, b)
+
+
+def test_b3_accumulation_bias_k_sweep(monkeypatch):
+    """the split-bf16 kernels carry a COHERENT error -- v_mfma_f32_32x32x16_bf16 accumulates with a floor-like bias
+    (DESIGN.md section 4), so the mean signed error of an output ("dc", relative to the output rms) does not average out over pixels
+    and ends up in every pixel-summed gradient (activation biases).  Sweep of the contraction length K = 9 Cin from 288 to 18 432 on
+    3x3 convolutions with leaky-ReLU-shaped inputs: dc and rms error of the direct and the Winograd split kernels and of the f32-MFMA
+    kernel against f64, printed as a table.  Measured (MI355X): dc grows LINEARLY in K -- direct -1.7e-8 / -6.3e-8 / -2.2e-7 / -4.3e-7 /
+    -8.0e-7 at K = 288 / 1152 / 4608 / 9216 / 18432 (4.3-6.0e-11 per unit of K), Winograd a quarter of that (-6e-9 .. -2.3e-7: two
+    thirds of the products, and its transformed operands are sign-mixed); the f32-MFMA kernel stays below 1.5e-8 everywhere and the
+    rms errors of all three are equal (the f32 class at every K).  Asserted: |dc| <= 6e-11 K + 1e-8 (direct), 2e-11 K + 1e-8
+    (Winograd).  What the gradient tolerance rests on: a bias gradient sums ~65536 sign-alternating pixel gradients, which turns a dc
+    of 1.25e-7 into the 5e-5 floor of test_full_width_gradients_near_linear; the Winograd kernel (every 3x3/s1 layer of the path,
+    K <= 4608) sits at 6e-8 there and would cross the floor at K ~ 10 000, twice the widest layer; the direct kernel (stride-2 /
+    transposed layers, at most 128x128 output pixels at K = 4608) is at 2.2e-7 on a quarter of the pixels."""
+    from ideas_amd import _lib
+    from ideas_amd.op import conv as C
+    from ideas_amd.op.conv_plan import ConvGeom
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    rows = []
+    for ci, h in ((32, 64), (128, 48), (512, 24), (1024, 16), (2048, 12)):
+        co = 64
+        x = F.leaky_relu(torch.randn(2, ci, h, h), 0.2) * 2 ** 0.5
+        wt = torch.randn(co, ci, 3, 3)
+        gain = 1 / (ci * 9) ** 0.5
+        ref = F.conv2d(x.double(), wt.double(), padding=1) * gain
+        rms = float(ref.pow(2).mean().sqrt())
+        xg, wg = dev(x, True), dev(wt, True)
+        g = ConvGeom(3, 3, 1, 1, False)
+        stat = {}
+        for name, math_, b3w in (("b3 direct", _lib.F32_B3, False), ("b3 wino", _lib.F32_B3, True), ("f32 mfma", _lib.F32, False)):
+            monkeypatch.setattr(C, "MATH", math_)
+            monkeypatch.setattr(C, "B3_WINO", b3w)
+            monkeypatch.setattr(C, "WINOGRAD", False)
+            e = C.conv_fwd_raw(xg, wg, g, gain).double().cpu() - ref
+            stat[name] = (float(e.mean()) / rms, float(e.pow(2).mean().sqrt()) / rms)
+        rows.append((9 * ci, stat))
+        print("K = %5d: " % (9 * ci) + " | ".join("%s dc %+.2e rms %.2e" % (n, d, r) for n, (d, r) in stat.items()))
+    for K, stat in rows:
+        assert abs(stat["b3 direct"][0]) <= 6e-11 * K + 1e-8, (K, stat)
+        assert abs(stat["b3 wino"][0]) <= 2e-11 * K + 1e-8, (K, stat)
+        for n in ("b3 direct", "b3 wino"):
+            assert stat[n][1] <= 1.2 * stat["f32 mfma"][1] + 5e-8, (n, K, stat[n])      # rms error: the f32 kernel's class at every K
+        assert abs(stat["f32 mfma"][0]) <= 3e-8, (K, stat["f32 mfma"])
+    for K, stat in rows:
+        if K <= 4608:
+            assert abs(stat["b3 wino"][0]) < 1.25e-7 and abs(stat["b3 direct"][0]) < 2.5e-7, (K, stat)
