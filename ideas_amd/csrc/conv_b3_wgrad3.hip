@@ -176,17 +176,30 @@ __global__ __launch_bounds__(256, 2) void conv_b3_wgrad3_kernel(float* __restric
     const int wo = wave >> 1, wc = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int g_q = lane & 15, g_row = g_q >> 2, g_piece = g_q & 3, g_cblk = (lane >> 4) & 1;
-    // byte offset (inside a plane) of this lane's pointer for transpose block at pixel row r, channel block cb (16 channels)
-    auto tr_off = [&](int r, int cb) { return chunk_off(r, cb * 2 + (g_piece >> 1)) + (g_piece & 1) * 8; };
+    // Transpose reads with NO per-read address arithmetic.  A fragment = 8 consecutive pixel rows r0 + 8 lh .. + 7 of one channel
+    // (two transpose blocks of 4 rows); its byte address is chunk_off(r, c) with the 16-byte chunk XOR-swizzled by bit 1 of the row.
+    // That bit depends only on (r0 mod 4) and the lane (the lane's row offsets 8 lh and + 4 are multiples of 4), so with the ring
+    // position of a step known at compile time (the step loop is unrolled over the four ring positions) an address is one of FOUR
+    // lane registers per operand plus an immediate: ds_read_b64_tr_b16 v, v_base[r0 & 3] offset:imm.  (Computed per read, the 60
+    // reads of a step cost 145 vector instructions next to its 54 MFMAs -- 2.7 of the kernel's 3.9 VALU per MFMA; on this part
+    // every VALU instruction of a SIMD is time taken from its matrix pipe: cycles per MFMA ~ 32 + 4 x VALU per MFMA.)
+    auto lane_base = [&](unsigned region, int b, int cb) {
+        const int r = b + 8 * lh + g_row;
+        return region + (unsigned)(r * 128 + (((cb * 2 + (g_piece >> 1)) ^ ((((b + g_row) >> 1) & 1) << 2)) << 4) + (g_piece & 1) * 8);
+    };
     const unsigned ldsG = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sG;
     const unsigned ldsX = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sX;
+    unsigned baseG[4], baseX[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { baseG[b] = lane_base(ldsG, b, wo * 2 + g_cblk); baseX[b] = lane_base(ldsX, b, wc * 2 + g_cblk); }
     auto tr_ld = [&](unsigned addr) -> s16x4 {
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr);
     };
-    auto frag = [&](unsigned base, int plane_bytes, int pl, int r0, int cb) -> bf16x8 {
-        // 8 consecutive pixels r0 + 8 lh .. + 7 of channel cb*16 + (lane & 15): two transpose blocks of 4 rows
-        const s16x4 a = tr_ld(base + (unsigned)(pl * plane_bytes + tr_off(r0 + 8 * lh + g_row, cb)));
-        const s16x4 b = tr_ld(base + (unsigned)(pl * plane_bytes + tr_off(r0 + 8 * lh + 4 + g_row, cb)));
+    // r0: compile-time row (after unrolling); plane_off: pl * plane bytes
+    auto frag = [&](const unsigned (&base)[4], int plane_off, int r0) -> bf16x8 {
+        const unsigned a0 = base[r0 & 3] + (unsigned)(plane_off + (r0 & ~3) * 128);
+        const s16x4 a = tr_ld(a0);
+        const s16x4 b = tr_ld(a0 + 512u);
         const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
@@ -200,18 +213,16 @@ __global__ __launch_bounds__(256, 2) void conv_b3_wgrad3_kernel(float* __restric
     // Nine taps = 54 MFMAs per wave and step.  Two taps are multiplied at a time, alternating their accumulators (no MFMA reads the
     // accumulator the previous one writes), while the transpose reads of the NEXT two taps are already in flight: left to itself
     // the compiler issued two reads, waited for them, issued one MFMA (read latency exposed 30 times per step).
-    auto compute = [&](int n) {                            // task n completed an output row: window rows = tasks n-2, n-1, n
+    auto compute = [&](auto ph_) {                         // ring phase PH = n % 4 of the task that completed an output row
+        constexpr int PH = decltype(ph_)::value;
         bf16x8 fa[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) fa[pl] = frag(ldsG, L::GPLANE, pl, (n & 1) * 16, wo * 2 + g_cblk);
-        int rbase[3];
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty) rbase[ty] = ((n - 2 + ty) % NR) * XW;
+        for (int pl = 0; pl < 3; ++pl) fa[pl] = frag(baseG, pl * L::GPLANE, (PH & 1) * 16);
         auto loadB = [&](int tap, bf16x8 (&fb)[3]) {
             const int ty = tap / 3, tx = tap - 3 * ty;
-            const int r0 = rbase[ty] + (S == 1 ? tx : (tx & 1) * 17 + (tx >> 1));
+            const int r0 = ((PH + 2 + ty) % NR) * XW + (S == 1 ? tx : (tx & 1) * 17 + (tx >> 1));       // window rows = tasks n-2, n-1, n
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fb[pl] = frag(ldsX, L::XPLANE, pl, r0, wc * 2 + g_cblk);
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = frag(baseX, pl * L::XPLANE, r0);
         };
         bf16x8 fb[5][2][3];                                // [pair][tap of the pair][plane] (fully unrolled: plain registers)
         loadB(0, fb[0][0]);
@@ -242,28 +253,26 @@ __global__ __launch_bounds__(256, 2) void conv_b3_wgrad3_kernel(float* __restric
     lstore(st0, 0);
     __syncthreads();
     bool mma0 = k0.mma, mma1 = k1.mma, live0 = k0.live, live1 = k1.live;
-    int n = 0;
-    // two iterations per trip so that the stage registers alternate without copies
+    static_assert(NR == 4, "the step loop is unrolled over the ring positions");
+    // one step: task n (ring phase PH = n % 4, compile-time) is multiplied, task n + 1 scaled / split into LDS, task n + 2 loaded
+    auto step = [&](auto ph_, Stage& ld, const Stage& stg) {
+        constexpr int PH = decltype(ph_)::value;
+        const Task k2 = next_task();
+        gload(ld, k2);
+        if (live1) lstore(stg, PH + 1);                    // (lstore only uses its index mod 4 and mod 2)
+        if (mma0) compute(ph_);
+        __syncthreads();
+        mma0 = mma1; live0 = live1; mma1 = k2.mma; live1 = k2.live;
+    };
+    // four steps per trip, so that the ring position (and with it every LDS read address) is a constant; the stage registers alternate
     while (live0) {
-        {
-            const Task k2 = next_task();
-            gload(st0, k2);
-            if (live1) lstore(st1, n + 1);
-            if (mma0) compute(n);
-            __syncthreads();
-            mma0 = mma1; live0 = live1; mma1 = k2.mma; live1 = k2.live;
-            ++n;
-        }
+        step(std::integral_constant<int, 0>{}, st0, st1);
         if (!live0) break;
-        {
-            const Task k2 = next_task();
-            gload(st1, k2);
-            if (live1) lstore(st0, n + 1);
-            if (mma0) compute(n);
-            __syncthreads();
-            mma0 = mma1; live0 = live1; mma1 = k2.mma; live1 = k2.live;
-            ++n;
-        }
+        step(std::integral_constant<int, 1>{}, st1, st0);
+        if (!live0) break;
+        step(std::integral_constant<int, 2>{}, st0, st1);
+        if (!live0) break;
+        step(std::integral_constant<int, 3>{}, st1, st0);
     }
 
     // ---- epilogue: D rows = o (r & 3) + 8 (r >> 2) + 4 lh, column = ci li; gw is OHWI ---------------------------------------------

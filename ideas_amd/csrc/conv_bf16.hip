@@ -1164,7 +1164,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad3_kernel(float* __restr
                                                                   int tiles_ci, int tiles, int splits, int strips, int parts,
                                                                   int rows_per_part, unsigned gy_bytes, unsigned x_bytes) {
     constexpr int XW = 40;                      // LDS pixels per window row (34 in use; 5 DMA pieces)
-    constexpr int NR = 5;                       // ring of window rows: 3 in use + 2 in flight
+    constexpr int NR = 6;                       // ring of window rows: 3 in use + 2 in flight (+ 1: the step loop is unrolled over the six ring
+                                                // positions, so that every LDS read address is a lane register + an immediate)
     constexpr int NG = 3;                       // G row buffers: 1 in use + 2 in flight
     constexpr int XBYTES = NR * XW * 128, GBYTES = NG * 32 * 128;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[XBYTES + GBYTES];
@@ -1228,66 +1229,67 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad3_kernel(float* __restr
     const int g_q = lane & 15, g_row = g_q >> 2, g_piece = g_q & 3, g_cblk = (lane >> 4) & 1;
     auto tr_off = [&](int r, int cb) { return w3_chunk_off(r, cb * 2 + (g_piece >> 1)) + (g_piece & 1) * 8; };
     const unsigned ldsG = (unsigned)(uintptr_t)LDS_PTR(sG), ldsX = (unsigned)(uintptr_t)LDS_PTR(sX);
-    auto tr_ld = [&](unsigned addr) -> s16x4 {
-        s16x4 v;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-        return v;
-    };
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    // per-lane byte offsets of the two transpose blocks of K-slice s (pixels 16 s + 8 lh + 0..7) at pixel offset tx, row slot 0
-    int offG[2][2], offX[3][2][2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            offG[s2][h] = tr_off(16 * s2 + 8 * lh + 4 * h + g_row, wo * 2 + g_cblk);
-#pragma unroll
-            for (int tx = 0; tx < 3; ++tx) offX[tx][s2][h] = tr_off(16 * s2 + 8 * lh + 4 * h + g_row + tx, wc * 2 + g_cblk);
-        }
+    // Transpose reads with NO per-read address arithmetic: the (r >> 1) & 1 swizzle of a pixel row depends only on (row mod 4) and the
+    // lane (row-slot bases XW * slot and 32 * buffer and the lane's row offsets 8 lh, 4 h are multiples of 4), so with the ring
+    // position a compile-time constant (loop unrolled over the six positions) an address is one of FOUR lane registers per operand
+    // (pixel offset tx + 16 s + ... mod 4) plus an immediate.  Computed per read they were ~40 of the ~60 vector instructions of a
+    // step, next to 18 MFMAs -- and a VALU instruction on a SIMD is time taken from its matrix pipe.
+    auto lane_base = [&](unsigned region, int b, int cb) {
+        const int r = b + 8 * lh + g_row;
+        return region + (unsigned)(r * 128 + (((cb * 2 + (g_piece >> 1)) ^ ((((b + g_row) >> 1) & 1) << 2)) << 4) + (g_piece & 1) * 8);
+    };
+    const unsigned baseG = lane_base(ldsG, 0, wo * 2 + g_cblk);
+    const unsigned bx0 = lane_base(ldsX, 0, wc * 2 + g_cblk), bx1 = lane_base(ldsX, 1, wc * 2 + g_cblk), bx2 = lane_base(ldsX, 2, wc * 2 + g_cblk);
+    (void)tr_off;
+#define TR_LD(dst, base, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(imm))
     f32x16 acc[9];
 #pragma unroll
     for (int a = 0; a < 9; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    dma(0);
-    dma(1);
-    for (int n = 0; n < ntask; ++n) {
-        wait_vmcnt<3>();                            // this wave's pieces of task n have landed (task n + 1's three stay in flight)
-        __builtin_amdgcn_s_barrier();               // ... and everybody else's; all waves are done with task n - 1's buffers
-        dma(n + 2);
-        if (n < 2) continue;                        // priming: the window is not complete yet (block-uniform)
-        const unsigned gb = ldsG + (unsigned)((n % NG) * 32 * 128);
-        unsigned xb[3];
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty) xb[ty] = ldsX + (unsigned)(((n - 2 + ty) % NR) * XW * 128);
-        // (the (r >> 1) & 1 swizzle of a row slot: XW * slot and 32 * buffer are multiples of 4, so it depends on the pixel only)
-        // The transpose reads are inline asm (see conv_bf16_wgrad_kernel), so the waits are placed by hand: LDS operations return in
-        // order, the reads of tap + 1 are issued before the MFMAs of tap, and lgkmcnt(4) = "everything but the last four reads".
+    // one step with ring phase PH = n % 6 (compile-time): G buffer PH % 3, window rows at slots (PH + 4 + ty) % 6
+    auto compute = [&](auto ph_) {
+        constexpr int PH = decltype(ph_)::value;
+        constexpr int GB = (PH % NG) * 32 * 128;
         s16x4 rg_[2][2], rx_[2][2][2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) rg_[s2][h] = tr_ld(gb + (unsigned)offG[s2][h]);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) rx_[0][s2][h] = tr_ld(xb[0] + (unsigned)offX[0][s2][h]);
+            for (int h = 0; h < 2; ++h) {
+                // pixel row 16 s2 + 4 h (+ 8 lh + g_row in the lane register): a multiple of 4 -> lane base 0
+                switch (s2 * 2 + h) {
+                    case 0: TR_LD(rg_[0][0], baseG, GB + 0 * 128); break;
+                    case 1: TR_LD(rg_[0][1], baseG, GB + 4 * 128); break;
+                    case 2: TR_LD(rg_[1][0], baseG, GB + 16 * 128); break;
+                    default: TR_LD(rg_[1][1], baseG, GB + 20 * 128); break;
+                }
+            }
+        // X fragment of tap (ty, tx), K-slice s2, half h: pixel row slot * XW + 16 s2 + 4 h + tx; XW * slot is a multiple of 4
+        auto readX = [&](auto tap_, s16x4 (&dst)[2][2]) {
+            constexpr int tap = decltype(tap_)::value;
+            constexpr int ty = tap / 3, tx = tap - 3 * ty;
+            constexpr int row0 = ((PH + 4 + ty) % NR) * XW;
+            // (row0 + 16 s2 + 4 h) is a multiple of 4: the lane base follows tx (0 .. 2)
+            const unsigned bb = tx == 0 ? bx0 : (tx == 1 ? bx1 : bx2);
+            TR_LD(dst[0][0], bb, (row0 + 0) * 128);
+            TR_LD(dst[0][1], bb, (row0 + 4) * 128);
+            TR_LD(dst[1][0], bb, (row0 + 16) * 128);
+            TR_LD(dst[1][1], bb, (row0 + 20) * 128);
+        };
+        readX(std::integral_constant<int, 0>{}, rx_[0]);
         bf16x8 fa[2];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) {
-                const int ty = (tap + 1) / 3, tx = (tap + 1) - 3 * ty;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) rx_[(tap + 1) & 1][s2][h] = tr_ld(xb[ty] + (unsigned)offX[tx][s2][h]);
+        auto tapstep = [&](auto tap_) {
+            constexpr int tap = decltype(tap_)::value;
+            if constexpr (tap < 8) {
+                readX(std::integral_constant<int, tap + 1>{}, rx_[(tap + 1) & 1]);
                 asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (tap == 0) {
+            if constexpr (tap == 0) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const s16x8 v = {rg_[s2][0][0], rg_[s2][0][1], rg_[s2][0][2], rg_[s2][0][3], rg_[s2][1][0], rg_[s2][1][1], rg_[s2][1][2], rg_[s2][1][3]};
@@ -1301,8 +1303,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_wgrad3_kernel(float* __restr
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2], __builtin_bit_cast(bf16x8, v), acc[tap], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        };
+        tapstep(std::integral_constant<int, 0>{}); tapstep(std::integral_constant<int, 1>{}); tapstep(std::integral_constant<int, 2>{});
+        tapstep(std::integral_constant<int, 3>{}); tapstep(std::integral_constant<int, 4>{}); tapstep(std::integral_constant<int, 5>{});
+        tapstep(std::integral_constant<int, 6>{}); tapstep(std::integral_constant<int, 7>{}); tapstep(std::integral_constant<int, 8>{});
+    };
+    static_assert(NR == 6 && NG == 3, "the step loop is unrolled over the ring positions");
+    // The transpose reads are inline asm (see conv_bf16_wgrad_kernel), so the waits are placed by hand: LDS operations return in
+    // order, the reads of tap + 1 are issued before the MFMAs of tap, and lgkmcnt(4) = "everything but the last four reads".
+    int n = 0;
+    auto step = [&](auto ph_) -> bool {
+        if (n >= ntask) return false;
+        wait_vmcnt<3>();                            // this wave's pieces of task n have landed (task n + 1's three stay in flight)
+        __builtin_amdgcn_s_barrier();               // ... and everybody else's; all waves are done with task n - 1's buffers
+        dma(n + 2);
+        if (n >= 2) compute(ph_);                   // (n < 2: priming, the window is not complete yet -- block-uniform)
+        ++n;
+        return true;
+    };
+    dma(0);
+    dma(1);
+    while (step(std::integral_constant<int, 0>{}) && step(std::integral_constant<int, 1>{}) && step(std::integral_constant<int, 2>{}) &&
+           step(std::integral_constant<int, 3>{}) && step(std::integral_constant<int, 4>{}) && step(std::integral_constant<int, 5>{})) {}
+#undef TR_LD
     wait_vmcnt<0>();
 
     // ---- epilogue: D rows = o (r & 3) + 8 (r >> 2) + 4 lh, column = ci li; gw is OHWI ---------------------------------------------

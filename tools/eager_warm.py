@@ -86,7 +86,8 @@ def cost(g):
 def worker(path: str, idx: int, nproc: int):
     import torch
     import torch.nn.functional as F
-    torch.backends.cudnn.benchmark = True
+    # EAGER_WARM_BENCHMARK=0: MIOpen immediate mode (no per-shape search: only the default solver's kernels are compiled)
+    torch.backends.cudnn.benchmark = os.environ.get("EAGER_WARM_BENCHMARK", "1") != "0"
     geoms = json.load(open(path))
     geoms.sort(key=cost, reverse=True)
     mine = geoms[idx::nproc]
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--worker", type=int, default=-1)
     ap.add_argument("--geoms", default="")
+    ap.add_argument("--no-benchmark", action="store_true", help="cudnn.benchmark off in the workers (immediate mode, as eager_baseline.py --no-benchmark)")
     a = ap.parse_args()
     if a.worker >= 0:
         worker(a.geoms, a.worker, a.procs)
@@ -130,7 +132,8 @@ def main():
     print("recorded %d distinct convolution calls (%d in total) of one iteration at B = %d" % (len(geoms), sum(g[-1] for g in geoms), a.batch),
           flush=True)
     env = dict(os.environ, MIOPEN_USER_DB_PATH=os.path.abspath(os.path.join(a.dir, "db")),
-               MIOPEN_CUSTOM_CACHE_DIR=os.path.abspath(os.path.join(a.dir, "cache")), OMP_NUM_THREADS="2")
+               MIOPEN_CUSTOM_CACHE_DIR=os.path.abspath(os.path.join(a.dir, "cache")), OMP_NUM_THREADS="2",
+               EAGER_WARM_BENCHMARK="0" if a.no_benchmark else "1")
     t0 = time.time()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(i), "--procs", str(a.procs), "--geoms", path],
                               env=env) for i in range(a.procs)]
