@@ -7,21 +7,23 @@
 // The generic kernel (conv_b3.hip) behind a blur pass costs: one HBM-bound pass over the largest tensors of a discriminator (8.6 % of the
 // f32 step's kernel time, half of it forward), and per conv block a load + split of every blurred pixel for each of its nine taps.
 // Here a block owns a patch of 8 x 16 output pixels and, per 16-channel chunk, builds the 17 x 33 blurred pixels under them ONCE:
-//   * FIR stage (408 of the 512 threads: 6 row segments x 17 column pairs x 4 channel quads): a thread walks down 6 raw rows with
-//     five 16-byte buffer loads per row (zero padding = an out-of-range offset), keeps the horizontally filtered pair of each row and
-//     emits 3 (2) blurred rows of its column pair -- the arithmetic of blur4_f32_c2 (upfirdn2d.hip), same taps, same FMA order;
+//   * four PRODUCER waves (one per SIMD) run the FIR: lane (channel quad, raw column) loads one 16-byte piece per raw row and walks
+//     down the 20 raw rows of the patch; the three other horizontal taps come from the lanes to the right by DPP row shifts, the
+//     vertical taps from the last four filtered rows in registers -- the arithmetic of blur4_f32_c2 (upfirdn2d.hip), same taps,
+//     same FMA order, so the blurred values (and with them the kernel's result) are bitwise those of the two-kernel chain;
 //   * the blurred values are split into the three bf16 planes and stored as a pixel-major LDS image (= the MFMA A layout), columns
 //     de-interleaved by parity (even columns at slots 0..16, odd at 17..32 of a 40-slot image row) so that the stride-2 tap (ty, tx)
 //     of 16 consecutive output pixels is 16 consecutive slots: a tap is a row address, as in conv_b3_tphase.hip;
-//   * eight waves (2 pixel halves x 4 channel groups; 4 x 2 for <= 64 output channels) multiply the nine taps from that image while
-//     the FIR stage builds the next chunk's image in the other LDS buffer (2 x 64 KB, one block per CU, one barrier per chunk); the
-//     weights ([3][chunk * 9 + tap][Cout][16], the planes of ideas_b3_split_weights) go straight from global memory into operand
-//     registers one tap ahead, as in conv_b3_wino.hip.
-// LDS slot s of the image holds 16 bf16 (32 B) per plane, 16-byte halves swapped when bit 3 of s is set; with the 40-slot pitch the two
+//   * four or eight CONSUMER waves (all 128 pixels x 32 output channels each for the 128 / 256-channel tiles) multiply the nine taps
+//     from the image of chunk c while the producers build chunk c + 1 in the other LDS buffer (2 x 64 KB, one block per CU, one
+//     barrier per chunk); the weights ([3][chunk * 9 + tap][Cout][16], the planes of ideas_b3_split_weights) go straight from global
+//     memory into operand registers two taps ahead.
+// LDS slot s of the image holds 16 bf16 (32 B) per plane, 16-byte halves swapped when bit 3 of s is set; with the 40-slot pitch the
 // pixel rows of an operand (80 slots apart) alias mod 16 slots, so every ds_read_b128 lane group covers 16 distinct (slot mod 8, half)
 // pairs: conflict-free at all nine taps (enumerated with tools/lds_conflicts_s2fir.py against the lane groups of MI355X_MICROARCH.md).
-// `xb_out` (optional): the blocks of channel tile 0 also store the blurred f32 values -- the operand of the layer's weight gradient
-// (conv_b3_wgrad.hip reads it as before); the store rides in a kernel that is bound by the matrix pipe, not by HBM.
+// `xb_out` (optional): the producers of channel tile 0 also store the blurred f32 values -- the operand of the layer's weight gradient
+// (conv_b3_wgrad.hip reads it as before).  Measurements, the ablations behind this shape and what the fusion can and cannot buy:
+// DESIGN.md section 3.9.
 #include "b3.hpp"
 #include <cstdlib>
 
