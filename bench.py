@@ -99,7 +99,7 @@ def roofline_probe_bf16(device, batch: int, launches: int):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     alg_bytes = 2.0 * batch * 256 * 256 * 128 * 2          # read x + write y, bf16
-    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "r03_pmc_bf16") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "r04_pmc_bf16") if batch == 32 else (None, None)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": note,
             "kernel": "conv_bf16_img_kernel<64,2,true> (the activation operand as an LDS image: one DMA of the 6 x 66 input pixels per 32-channel "
@@ -146,7 +146,7 @@ def roofline_probe(device, batch: int, launches: int):
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         b3w = CV.B3_WINO
         kname = "conv_b3_wino2d_kernel" if b3w else "conv_b3_kernel"
-        traffic, traffic_note = _pmc_traffic(kname, "r03_pmc_b3w" if b3w else "r03_pmc_b3") if batch == 32 else (None, None)
+        traffic, traffic_note = _pmc_traffic(kname, "r04_pmc_b3w" if b3w else "r04_pmc_b3") if batch == 32 else (None, None)
         executed = achieved * (4.0 if b3w else 6.0)       # bf16 MFMA FLOPs issued per algorithmic f32 FLOP
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -211,7 +211,7 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and (bf16 or (CV.MATH == _lib.F32_B3 and not CV.B3_WINO_WGRAD)):
-        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r03_pmc_bf16wg" if bf16 else "r03_pmc_b3wg")
+        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r04_pmc_bf16wg" if bf16 else "r04_pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, column strips x row ranges in "
             "XCD-banded order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
@@ -241,7 +241,7 @@ def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
     ms = e0.elapsed_time(e1) / launches
     nbytes = (batch * 128 * 256 * 256 + batch * 128 * 257 * 257) * (2 if bf16 else 4)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r03_pmc_blurbf16" if bf16 else "r03_pmc_blurf32") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r04_pmc_blurbf16" if bf16 else "r04_pmc_blurf32") if batch == 32 else (None, None)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
             "traffic_source": note,
             "kernel": ("blur4_bf16x8_c2<0>" if bf16 else "blur4_f32_c2<0>") + " (4x4 FIR of a downsampling ConvLayer, two output columns per thread) on "
@@ -295,7 +295,7 @@ def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and not bf16 and CV.MATH == _lib.F32_B3:
-        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "r03_pmc_b3tp")
+        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "r04_pmc_b3tp")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on G.layers.7.conv1: stride-2 transposed 3x3 modconv 256->128, 128x128 -> 257x257, B=%d "
             "(all output-parity phases of the layer)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),

@@ -9,6 +9,10 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/$1
 WHAT=${2:-both}
 mkdir -p $OUT
+# Evidence discipline: the set is taken of ONE source state and says which.  HEAD.txt = a hash over every tracked
+# source of the kernels and the bench (the GPU box has no .git: the snapshot is what `git ls-files` would list plus nothing else that
+# matters); tools/check_evidence.py compares it with the working tree before profiles/ is committed and refuses a mismatch.
+python $R/tools/check_evidence.py --write $OUT/HEAD.txt
 cd /tmp && export TMPDIR=/tmp
 sha() { python - "$@" <<'EOF'
 import hashlib, json, os, sys
@@ -36,6 +40,7 @@ run_one() {   # $1 = precision, $2 = tag, $3 = weight-gradient kernel source, $4
   sha $OUT/${T}_wgrad_source.json $WG b3.hpp common.hpp
   sha $OUT/${T}_blur_source.json upfirdn2d.hip common.hpp
   sha $OUT/${T}_direct_source.json conv_b3_tphase.hip b3.hpp common.hpp
+  sha $OUT/${T}_s2_source.json conv_b3_s2fir.hip b3.hpp common.hpp
 }
 if [ "$WHAT" = "f32" ] || [ "$WHAT" = "both" ]; then run_one f32 f32 conv_b3_wgrad3.hip conv_b3_wino.hip b3.hpp common.hpp; fi
 if [ "$WHAT" = "bf16" ] || [ "$WHAT" = "both" ]; then run_one bf16 bf16 conv_bf16.hip conv_bf16.hip common.hpp; fi

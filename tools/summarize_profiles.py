@@ -17,6 +17,7 @@ KERNEL = {"f32": "conv_b3_wino2d_kernel", "bf16": "conv_bf16_img_kernel"}
 WGRAD = {"f32": ("conv_b3_wgrad3_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad3_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
 BLUR = {"f32": ("blur4_f32_c2", "blurf32"), "bf16": ("blur4_bf16x8_c2", "blurbf16")}                 # bench.py's roofline_hbm entry
 DIRECT = {"f32": ("conv_b3_tphase_kernel", "b3tp"), "bf16": (None, None)}                            # bench.py's roofline_direct entry
+S2 = {"f32": ("conv_b3_s2fir_kernel", "b3s2"), "bf16": (None, None)}                                 # bench.py's roofline_s2 entry
 NAMES = {"fetch_size": "fetch_size", "write_size": "write_size", "sq_wave_cycles": "sq_wave", "sq_insts_valu": "sq_insts",
          "sq_lds_bank_conflict": "lds_grbm"}
 for tag, kern in KERNEL.items():
@@ -36,9 +37,11 @@ for tag, kern in KERNEL.items():
         wk, wtag = WGRAD[tag]
         bk, btag = BLUR[tag]
         dk, dtag = DIRECT[tag]
+        sk, stag = S2[tag]
         for kname, prefix in ((kern, pre), (wk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wtag}")),
                               (bk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{btag}")),
-                              (dk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{dtag}"))):
+                              (dk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{dtag}")),
+                              (sk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{stag}"))):
             if kname is None:
                 continue
             keep = [r for r in rows if kname + "<" in r["Kernel_Name"] or kname + "(" in r["Kernel_Name"]]
@@ -55,4 +58,8 @@ for tag, kern in KERNEL.items():
         shutil.copy(os.path.join(src, tag + "_wgrad_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{WGRAD[tag][1]}_source.json"))
     if DIRECT[tag][0] and os.path.exists(os.path.join(src, tag + "_direct_source.json")):
         shutil.copy(os.path.join(src, tag + "_direct_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{DIRECT[tag][1]}_source.json"))
+    if S2[tag][0] and os.path.exists(os.path.join(src, tag + "_s2_source.json")):
+        shutil.copy(os.path.join(src, tag + "_s2_source.json"), os.path.join(ROOT, "profiles", f"{rnd}_pmc_{S2[tag][1]}_source.json"))
+    if os.path.exists(os.path.join(src, "HEAD.txt")):
+        shutil.copy(os.path.join(src, "HEAD.txt"), os.path.join(ROOT, "profiles", f"{rnd}_evidence_head.txt"))
     print(tag, "->", pre + "_*")
