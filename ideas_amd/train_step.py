@@ -103,7 +103,6 @@ def graph_small_nets(trainer, args, batch: int, image_size: int, device="cuda", 
 
 
 @dataclass
-class StepDraws:@dataclass
 class StepDraws:
     """Every random draw of one iteration, in program order.  Z/T2 are already mapped to U(-1, 1)."""
     Z_d: torch.Tensor = None
