@@ -681,8 +681,6 @@ def run_steps(a, precision_name, steps, warmup, device, world, rank):
     if not a.torch_adam:
         from ideas_amd.optim import fuse_optimizers
         fuse_optimizers(trainer, args)      # one fused Adam(beta1=0)+EMA launch per group on flat buffers
-    if os.environ.get("IDEAS_GRAPH_SMALL", "0") == "1":
-        TS.graph_small_nets(trainer, args, a.batch, a.image_size, device)     # Gstru / Ex forward + backward as HIP graphs (opt-in)
     random.seed(1000 + rank)
     torch.manual_seed(1000 + rank)
     gx = torch.Generator().manual_seed(1234 + rank)

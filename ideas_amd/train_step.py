@@ -77,31 +77,6 @@ def build_trainer(args, device, init_model: Callable, with_ema: bool = True, dco
     return t
 
 
-def graph_small_nets(trainer, args, batch: int, image_size: int, device="cuda", nets=("Gstru", "Ex")):
-    """Capture forward and backward of the two tiny networks in HIP graphs (torch.cuda.make_graphed_callables).
-
-    Gstru (models.py:309-329) and Ex (models.py:444-465) are 0.2 GFLOP each at 16x16 -- ~45 launches forward and ~120 backward of
-    5-20 us kernels apiece, whose cost is the dependency latency between them, not their work.  A captured graph replays the same
-    kernels (our C-ABI launches enqueue on the capture stream like any other) as one submission.  The derived weights (split planes /
-    bf16 packs) are part of the captured work: they are remade from the current parameters at every replay, so optimiser steps
-    need no bookkeeping.  Shapes are static: the trainer must keep calling the networks with ``batch`` samples; the activation
-    precision at capture time is baked in.  Weight and bias gradients come back through autograd (the gradient sink of op/conv.py
-    is not consulted inside a graph) and are accumulated into ``.grad`` as for any other module.  Opt-in: IDEAS_GRAPH_SMALL=1 in
-    bench.py / train.py."""
-    from .precision import activation_dtype
-    s = image_size // 16
-    samples = {"Gstru": (torch.rand(batch, args.N, s, s, device=device) * 2 - 1,),
-               "Ex": (torch.randn(batch, args.structure_channel, s, s, device=device).contiguous(memory_format=torch.channels_last).requires_grad_(True),)}
-    conv_plan.cache_end()        # (the capture must see no derived-weight cache: see above)
-    for n in nets:
-        m = trainer[n]
-        for p in m.parameters():
-            p.requires_grad_(True)
-        trainer[n] = torch.cuda.make_graphed_callables(m, samples[n], num_warmup_iters=3)
-    trainer["_graphed"] = (tuple(nets), batch, str(activation_dtype()))
-    return trainer
-
-
 @dataclass
 class StepDraws:
     """Every random draw of one iteration, in program order.  Z/T2 are already mapped to U(-1, 1)."""
