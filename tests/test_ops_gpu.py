@@ -849,6 +849,8 @@ def test_batched_weight_refill_is_bitwise_the_single_launches():
                         out.append(CV.bf16_pack(Ld))
         return out
     from ideas_amd.precision import activations
+    for d in (conv_plan._RECORDED, conv_plan._PREP_STATE, conv_plan._KEYS_OF, conv_plan._OUT_BUF):
+        d.clear()                                         # (what earlier tests of this process remembered is not this test's business)
     conv_plan.cache_begin()
     try:
         first = forms()                                   # misses: made one by one and remembered
@@ -887,6 +889,7 @@ def test_batched_weight_refill_is_bitwise_the_single_launches():
     conv_plan._RECORDED.clear()                           # (what this test remembered must not leak into later tests' refills)
     conv_plan._PREP_STATE.clear()
     conv_plan._KEYS_OF.clear()
+    conv_plan._OUT_BUF.clear()
 
 
 def test_b3_transposed_phases_full_size(monkeypatch):
