@@ -803,6 +803,7 @@ class _ConvBiasActBlur(Function):
 # ----------------------------------------------------------------------------------------------------
 BLUR_CONV = _os.environ.get("IDEAS_BLUR_CONV", "1") != "0"
 BLUR_CONV_MIN_OW = int(_os.environ.get("IDEAS_BLUR_CONV_MIN_OW", "16"))      # below: the 8 x 16 output patch of the kernel would idle
+BLUR_CONV_MIN_BLOCKS = int(_os.environ.get("IDEAS_BLUR_CONV_MIN_BLOCKS", "512"))   # down_pair_ok: below, the two-kernel chain wins
 
 
 def fir_factors(fir: torch.Tensor, flip: bool = True):
@@ -955,7 +956,12 @@ def down_pair_ok(input: torch.Tensor, w1, w2, fir, pad2, padding1: int = 1) -> b
         return False
     if torch.is_grad_enabled() and w2.requires_grad and not (pl[1] == 2 * pl[0].OH + 1 and pl[2] == 2 * pl[0].OW + 1):
         return False
-    return True
+    # Fewer than two workgroups per CU: every block's producers repeat the blur for its N tile and nothing hides the tail, the
+    # blur kernel + generic stride-2 conv is as fast or faster (profiles/r04_blur_conv_microbench.txt: E.4.conv2 0.29 against 0.25 ms,
+    # Dreal.4.conv2 a tie)
+    L = pl[0]
+    nt = 256 if L.Cout > 128 else 128 if L.Cout > 64 else 64
+    return L.B * ((L.OH + 7) // 8) * ((L.OW + 15) // 16) * ((L.Cout + nt - 1) // nt) >= BLUR_CONV_MIN_BLOCKS
 
 
 def down_pair(input: torch.Tensor, w1, b1, w2, b2, fir, pad2, padding1: int = 1, reflect1: bool = False, gain1: float = 1.0,

@@ -1450,7 +1450,7 @@ def test_blur_conv_s2_vs_oracle(case):
 
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 64, "zero"), (1, 16, 128, 32, 48, "reflect"), (2, 64, 256, 32, 32, "zero"), (1, 16, 32, 16, 32, "zero")])
 @pytest.mark.parametrize("freeze2", [False, True])
-def test_down_pair_gradients_vs_oracle(case, freeze2):
+def test_down_pair_gradients_vs_oracle(case, freeze2, monkeypatch):
     """op.conv.down_pair (conv1 -> [Blur -> stride-2 conv2] of a downsampling ResBlock body as one autograd node, models.py:185-187):
     forward and every gradient against the f64 composite; with conv2 frozen (the G phase's discriminator passes) no blurred tensor
     is written at all."""
@@ -1475,6 +1475,7 @@ def test_down_pair_gradients_vs_oracle(case, freeze2):
     if freeze2:
         w2d.requires_grad_(False); b2d.requires_grad_(False)
     fd = fir.cuda()
+    monkeypatch.setattr(convmod, "BLUR_CONV_MIN_BLOCKS", 0)
     assert convmod.down_pair_ok(xd, w1d, w2d, fd, (2, 2), 1)
     yd = convmod.down_pair(xd, w1d, b1d, w2d, b2d, fd, (2, 2), padding1=1, reflect1=padding == "reflect", gain1=s1, gain2=s2,
                            scale2=math.sqrt(2) * 0.7)
@@ -1525,6 +1526,8 @@ def test_downsampling_resblock_fused_blur_conv_equals_layerwise_path(monkeypatch
     """ResBlock.forward with the Blur inside conv2's kernel vs the layer-by-layer path (IDEAS_BLUR_CONV=0) on the same weights: outputs
     and parameter / input gradients agree to the kernels' rounding, under autograd and under no_grad (residual in the epilogue)."""
     import ideas_amd.models as M
+    from ideas_amd.op import conv as C
+    monkeypatch.setattr(C, "BLUR_CONV_MIN_BLOCKS", 0)          # the model only fuses grids of >= 2 blocks per CU; this one is small
     torch.manual_seed(5)
     blk = M.ResBlock(32, 64, downsample=True).cuda()
     for n_, p_ in blk.named_parameters():
@@ -1533,6 +1536,11 @@ def test_downsampling_resblock_fused_blur_conv_equals_layerwise_path(monkeypatch
     x = dev(torch.randn(2, 32, 64, 64), True).requires_grad_(True)
     gy = dev(torch.randn(2, 64, 32, 32), True)
     res = {}
+    blk._fused = blk._fused_body()
+    assert blk._fused is not None and blk._body_pair_ok(x)
+    monkeypatch.setattr(C, "BLUR_CONV_MIN_BLOCKS", 10 ** 9)
+    assert not blk._body_pair_ok(x)
+    monkeypatch.setattr(C, "BLUR_CONV_MIN_BLOCKS", 0)
     for fused in (True, False):
         monkeypatch.setattr(M, "FUSE_BLUR_CONV", fused)
         y = blk(x)

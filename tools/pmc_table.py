@@ -4,7 +4,7 @@
 import csv, os, sys, collections
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-for pre in ("b3w", "b3wg", "b3tp", "bf16", "bf16wg", "blurf32", "blurbf16"):
+for pre in ("b3w", "b3wg", "b3tp", "b3s2", "bf16", "bf16wg", "blurf32", "blurbf16"):
     vals, dur, name = collections.defaultdict(list), [], None
     for cs in ("fetch_size", "write_size", "sq_wave", "sq_insts", "lds_grbm"):
         f = os.path.join(root, f"{rnd}_pmc_{pre}_{cs}.csv")
