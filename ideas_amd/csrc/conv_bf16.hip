@@ -837,7 +837,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_wgrad_kernel(float* __
         w_oy[j] = qq - w_b[j] * p.OH;
         w_p[j] = pp;
     }
-    const int d_ox = 32 % p.OW, d_oy = 32 / p.OW;   // (32 | OW: d_oy = 0;  OW | 32: d_ox = 0)
+    // a step advances 32 pixels of the flattened (b, oy, ox) axis.  32 | OW: d_oy = 0;  OW | 32: d_ox = 0;  images of <= 32 pixels
+    // whose size divides 32 (the <= 4 x 4 maps of the co-occurrence discriminator's tail): 32 / OHW whole samples, same pixel
+    const int d_b = (OHW <= 32 && 32 % OHW == 0) ? 32 / OHW : 0;
+    const int d_ox = d_b ? 0 : 32 % p.OW, d_oy = d_b ? 0 : 32 / p.OW;
 
     auto dma = [&](int buf) {
         unsigned char* base = smem + buf * BUF;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_bf16_wgrad_kernel(float* __
             w_oy[j] += d_oy + (cx ? 1 : 0);
             const bool cy = w_oy[j] >= p.OH;
             w_oy[j] -= cy ? p.OH : 0;
-            w_b[j] += cy ? 1 : 0;
+            w_b[j] += d_b + (cy ? 1 : 0);
         }
     };
 
@@ -1049,7 +1052,8 @@ extern "C" int ideas_bf16_wgrad_supported(const ideas_conv_params* p, int scaled
     if (!p) return 0;
     const int64_t P = (int64_t)p->B * p->OH * p->OW;
     if (p->Cin % 8 || p->Cout % 8) return 0;
-    if (!(p->OW % 32 == 0 || 32 % p->OW == 0) || 32 / p->OW > p->OH) return 0;
+    const int64_t ohw = (int64_t)p->OH * p->OW;
+    if (!(ohw <= 32 && 32 % ohw == 0) && (!(p->OW % 32 == 0 || 32 % p->OW == 0) || 32 / p->OW > p->OH)) return 0;
     if (P >= 0x7fffffffLL || (int64_t)p->B * p->IH * p->IW * p->Cin * 2 >= 0xffffffffLL ||
         (int64_t)p->B * p->YH * p->YW * p->Cout * 2 >= 0xffffffffLL)
         return 0;

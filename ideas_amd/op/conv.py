@@ -372,13 +372,14 @@ def _wino_fold(gu, out, co: int, ci: int, w_shape, device, clear: bool = True):
 
 
 # Weight gradients of the layers with <= 4x4 output pixels per sample and many samples (the co-occurrence discriminator's last
-# blocks: 1024 patches of 2x2 .. 4x4): as an implicit GEMM over pixels most of a 32-pixel K-step is another sample's padding, and the
-# kernels ran at 50-140 TFLOP/s (7 ms of the bf16 iteration, on f32 kernels behind casts).  Here the im2col matrix is tiny (a few tens
-# of MB), so it is materialised (one cat of the KH*KW shifted views of the padded NHWC tensor) and the gradient is ONE library GEMM
-# [Cout, P] x [P, KH*KW*Cin] (hipBLASLt, f32 accumulation and output) -- the OHWI matrix exactly.  Same box, bf16 iteration:
-# 172.4 -> 169.7 ms.  With f32 activations the library's f32 GEMM is no faster than the b3 kernels (449.4 -> 451.5 ms), so the
-# default (1) takes this path for bf16 activations only; IDEAS_TINY_WGRAD_GEMM=2: f32 too (the parity tests run it), 0: off.
-TINY_WGRAD_GEMM = int(_os.environ.get("IDEAS_TINY_WGRAD_GEMM", "1"))
+# blocks: 1024 patches of 2x2 .. 4x4).  Round 3 sent them to ONE library GEMM [Cout, P] x [P, KH*KW*Cin] (hipBLASLt) on a materialised
+# im2col (one cat of the KH*KW shifted views of the padded NHWC tensor), because conv_bf16_wgrad_kernel did not cover images narrower
+# than its 32-pixel K-step and those layers fell to the f32 kernels behind casts (50-140 TFLOP/s).  Round 4: the kernel's K-step
+# advances by whole samples when the image size divides 32 (csrc/conv_bf16.hip), every pixel of a step is a real output pixel, and
+# it beats the GEMM on every shape of tools/tiny_wgrad_scan.py (1024 x 2x2 768->768: 0.095 against 0.176 ms; 1024 x 4x4 384->384:
+# 0.095 / 0.263; 256 x 2x2 384->768: 0.040 / 0.075) without the cat / pad composites.  Default 0 = the HIP kernels;
+# IDEAS_TINY_WGRAD_GEMM=1: the GEMM for bf16 activations (A/B), 2: f32 too (tests/test_bf16_gpu.py runs both against f64).
+TINY_WGRAD_GEMM = int(_os.environ.get("IDEAS_TINY_WGRAD_GEMM", "0"))
 PRESCALE_MOD_PIX = int(_os.environ.get("IDEAS_PRESCALE_MOD_PIX", "256"))
 TINY_MAX_PIX = int(_os.environ.get("IDEAS_TINY_MAX_PIX", "16"))
 TINY_MAX_PIX_MOD = int(_os.environ.get("IDEAS_TINY_MAX_PIX_MOD", "16"))

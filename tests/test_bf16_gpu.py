@@ -77,7 +77,7 @@ CONV_CASES = [
     # conv_bf16_wgrad3_kernel (tap-fused weight gradient: Cin, Cout % 64 == 0, W % 32 == 0): three strips, several parts per image,
     # a 2 x 2 grid of channel tiles (the cases (2, 64, 128, .., 8, 64) above -- plain and mirror-padded -- take it as well)
     (3, 64, 64, 3, 1, 1, False, 40, 96), (2, 128, 128, 3, 1, 1, False, 16, 32),
-    # many samples of <= 4x4 output pixels: weight gradient as one library GEMM (op/conv.py::_tiny_spatial_wgrad)
+    # many samples of <= 4x4 output pixels (K-steps of whole samples, csrc/conv_bf16.hip; test_tiny_spatial_weight_gradient_vs_f64)
     (300, 64, 96, 3, 1, 1, False, 2, 2), (80, 64, 64, 3, 2, 0, False, 9, 9),
 ]
 
@@ -103,6 +103,46 @@ def test_conv_bf16_vs_f64_on_rounded_operands(ops, bf16_mode, case):
     assert gxd.dtype == BF and gwd.dtype == torch.float32
     close_bf16(gxd, gx, ("gx", case), roundings=3 if refl else 1)    # reflect: the padded gradient is rounded, then folded
     assert rel_err(gwd, gw) < 1e-3, ("gw", case, rel_err(gwd, gw))
+
+
+TINY_WGRAD_CASES = [
+    # B, Cin, Cout, k, stride, pad, H, W, modulated       (<= 4 x 4 output pixels per sample: 32-pixel K-steps span whole samples)
+    (300, 64, 96, 3, 1, 1, 2, 2, False), (80, 64, 64, 3, 2, 0, 9, 9, False), (257, 64, 128, 3, 1, 1, 4, 4, False),
+    (130, 128, 64, 3, 1, 1, 1, 1, False), (70, 64, 64, 3, 1, 1, 2, 4, False), (64, 64, 72, 1, 1, 0, 4, 2, False),
+    (40, 64, 64, 3, 1, 1, 4, 4, True), (33, 96, 64, 3, 2, 0, 5, 5, False),
+]
+
+
+@pytest.mark.parametrize("case", TINY_WGRAD_CASES)
+@pytest.mark.parametrize("gemm", [0, 1])
+def test_tiny_spatial_weight_gradient_vs_f64(monkeypatch, case, gemm):
+    """Weight gradients of the layers with <= 4 x 4 output pixels and many samples (Dco's tail: 1024 patches of 2 x 2 .. 4 x 4).
+    Default (IDEAS_TINY_WGRAD_GEMM=0): conv_bf16_wgrad_kernel, whose 32-pixel K-step advances by whole samples when the image size
+    divides 32 (csrc/conv_bf16.hip) -- no im2col, no library GEMM; 1: round 3's hipBLASLt GEMM on a materialised im2col, kept for
+    A/B.  Both against f64 on the same bf16-rounded operands, with and without per-sample scales."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    monkeypatch.setattr(CV, "TINY_WGRAD_GEMM", gemm)
+    B, ci, co, k, st, pad, H, W, mod = case
+    torch.manual_seed(sum(case[:8]))
+    x = bf(torch.randn(B, ci, H, W, dtype=torch.float64))
+    oh, ow = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    gy = bf(torch.randn(B, co, oh, ow, dtype=torch.float64))
+    lin = (torch.rand(B, ci) + 0.5) if mod else None
+    lout = (torch.rand(B, co) + 0.5) if mod else None
+    gain = 0.37
+    w = torch.zeros(co, ci, k, k, dtype=torch.float64, requires_grad=True)
+    if mod:     # the kernels round the scaled operands once (the small-image modulated path, op/conv.py)
+        xs, gs = bf(x * lin.double()[:, :, None, None]), bf(gy * lout.double()[:, :, None, None])
+    else:
+        xs, gs = x, gy
+    ref, = torch.autograd.grad(F.conv2d(xs, w, stride=st, padding=pad) * gain, w, gs)
+    g = ConvGeom(k, k, st, pad, False)
+    out = torch.full((co, ci, k, k), 0.5, device="cuda").contiguous(memory_format=CL)
+    got = CV.conv_wgrad_raw(dev(gy, dtype=BF), dev(x, dtype=BF), g, (co, ci, k, k), gain,
+                            None if lin is None else lin.cuda(), None if lout is None else lout.cuda(), out=out)
+    assert got.dtype == torch.float32
+    assert rel_err(got - 0.5, ref) < (2e-3 if mod else 2e-5), (case, gemm, rel_err(got - 0.5, ref))
 
 
 def test_bf16_image_and_tap_fused_kernels_full_size(monkeypatch):

@@ -109,6 +109,7 @@ def worker(path: str, idx: int, nproc: int):
             print(f"[worker {idx}] {kind} {xs} {ws}: {type(e).__name__}: {e}", flush=True)
         del x, w
         torch.cuda.empty_cache()
+        print(f"[worker {idx}] {i + 1}/{len(mine)} {kind} x{tuple(xs)} w{tuple(ws)} s{stride} g{groups} at {time.time() - t0:.0f} s", flush=True)
     print(f"[worker {idx}] {len(mine)} geometries in {time.time() - t0:.0f} s", flush=True)
 
 
@@ -120,6 +121,8 @@ def main():
     ap.add_argument("--worker", type=int, default=-1)
     ap.add_argument("--geoms", default="")
     ap.add_argument("--no-benchmark", action="store_true", help="cudnn.benchmark off in the workers (immediate mode, as eager_baseline.py --no-benchmark)")
+    ap.add_argument("--deadline", type=float, default=0.0, help="seconds after which the workers still running are killed (by pid); what "
+                    "they compiled so far stays in the db / cache directory, so a later call resumes from it")
     a = ap.parse_args()
     if a.worker >= 0:
         worker(a.geoms, a.worker, a.procs)
@@ -137,6 +140,13 @@ def main():
     t0 = time.time()
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(i), "--procs", str(a.procs), "--geoms", path],
                               env=env) for i in range(a.procs)]
+    if a.deadline > 0:
+        while time.time() - t0 < a.deadline and any(p.poll() is None for p in procs):
+            time.sleep(2.0)
+        left = [p for p in procs if p.poll() is None]
+        for p in left:
+            p.kill()
+        print("deadline %.0f s: %d of %d workers were still compiling and were stopped" % (a.deadline, len(left), a.procs), flush=True)
     rc = [p.wait() for p in procs]
     print("warm-up of the MIOpen db: %.0f s with %d processes, exit codes %s" % (time.time() - t0, a.procs, sorted(set(rc))), flush=True)
 
