@@ -31,7 +31,9 @@ namespace {
 
 constexpr int TR = 8, TP = 16;                 // output patch
 constexpr int IR = 2 * TR + 1;                 // image rows per chunk: 17
-constexpr int PITCH = 40, ODD0 = 17;           // slots per image row; first slot of the odd columns
+constexpr int PITCH = 40, ODD0 = 24;           // slots per image row; first slot of the odd columns (17 even + 16 odd slots; ODD0 % 8 == 0
+                                               // with ODD0 / 8 odd: the odd run's 16-byte halves sit opposite the even run's, which keeps a
+                                               // producer's ds_write_b64 -- 16 lanes = 16 columns of one channel quad -- at 2-way instead of 4-way)
 constexpr int PLB = IR * PITCH * ROWB;         // bytes per plane: 21760
 constexpr int BUFB = 3 * PLB;                  // 65280
 constexpr int BW = 9;                          // image columns per producer wave (4 waves x 9 >= 33); a wave loads 16 raw columns
@@ -199,14 +201,16 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     // operand of tap (ty, tx), row block rb: image row 4 (wm RB + rb) + 2 (li >> 4) + ty, slot (li & 15) + {0, ODD0, 1}[tx].  Two lane
-    // addresses (tap column 0 and 2; the odd columns sit 16 slots behind the latter: same bit 3) plus immediates: + PITCH * ROWB per
-    // ty (halves swapped back for ty = 1), + 512 for tx = 1, + 4 * PITCH * ROWB per row block (bit 3 unchanged).
+    // addresses (tap column 0 and 2; the odd columns sit ODD0 = 3 x 8 slots behind the former: bit 3 flipped, halves swapped) plus
+    // immediates: + PITCH * ROWB per ty (halves swapped back for ty = 1), + ODD0 * ROWB for tx = 1, + 4 * PITCH * ROWB per row block
+    // (bit 3 unchanged).
     const int a_row0 = (4 * wm * RB + 2 * (li >> 4)) * PITCH + (li & 15);
     int a_c0 = slot_byte(a_row0, lh), a_c2 = slot_byte(a_row0 + 1, lh);
     auto a_off = [&](int tap, int rb) {
         const int ty = tap / 3, tx = tap - 3 * ty;
-        const int base = tx == 0 ? a_c0 : a_c2;
-        return ((ty & 1) ? (base ^ 16) : base) + ty * PITCH * ROWB + (tx == 1 ? (ODD0 - 1) * ROWB : 0) + rb * 4 * PITCH * ROWB;
+        static_assert(ODD0 % 8 == 0 && (ODD0 / 8) % 2 == 1, "tap column 1 = tap column 0's address with the halves swapped");
+        const int base = tx == 2 ? a_c2 : a_c0;
+        return ((((ty & 1) != 0) != (tx == 1)) ? (base ^ 16) : base) + ty * PITCH * ROWB + (tx == 1 ? ODD0 * ROWB : 0) + rb * 4 * PITCH * ROWB;
     };
     const unsigned b_voff = (unsigned)((n0 + wn * NB * 32 + li) * 32 + lh * 16);
     f32x16 acc[RB][NB];

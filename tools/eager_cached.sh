@@ -30,6 +30,10 @@ try:
 except Exception as e:
     print("no result: %s" % e)
 PY
+  # second figure, for the record: the same iteration with MIOPEN_FIND_MODE=FAST (no search at all: find-db hit or the heuristic
+  # immediate-mode solver) -- what a user gets who refuses the hours of search; never the headline comparator when the searched one exists
+  MIOPEN_FIND_MODE=FAST MIOPEN_USER_DB_PATH=$D/db MIOPEN_CUSTOM_CACHE_DIR=$D/cache timeout 400 python tests/eager_baseline.py --batch 32 --steps 3 --warmup 1 --no-benchmark > gpurun_out/eager_fast.json 2> gpurun_out/eager_fast.err
+  tail -2 gpurun_out/eager_fast.err; cat gpurun_out/eager_fast.json
 fi
 du -sh $D/db $D/cache
 # the tarballs: db (small) and cache (the compiled kernels), split so that one oversized part does not lose the other
