@@ -241,7 +241,7 @@ def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
     ms = e0.elapsed_time(e1) / launches
     nbytes = (batch * 128 * 256 * 256 + batch * 128 * 257 * 257) * (2 if bf16 else 4)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r04_pmc_blurbf16" if bf16 else "r04_pmc_blurf32") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r04_pmc_blurbf16" if bf16 else "r04_pmc_blurf32", smallest_grid=True) if batch == 32 else (None, None)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
             "traffic_source": note,
             "kernel": ("blur4_bf16x8_c2<0>" if bf16 else "blur4_f32_c2<0>") + " (4x4 FIR of a downsampling ConvLayer, two output columns per thread) on "
@@ -338,7 +338,7 @@ def roofline_probe_s2(device, batch: int, launches: int):
     finally:
         conv_plan.cache_end()
     tf = lambda ms: round(flops / (ms * 1e-3) / 1e12, 2)
-    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel", "r04_pmc_b3s2") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false>", "r04_pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
     alg = float(B3 * (256 * 256 + 128 * 128) * 128 * 4)
     return {"bound": "mfma", "achieved": tf(ms_f), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf(ms_f) / peak, 4), "traffic": traffic,
             "traffic_source": note,
@@ -380,12 +380,14 @@ def _src_sha(files):
     return h.hexdigest()[:16]
 
 
-def _pmc_traffic(kernel_substr: str, prefix: str):
+def _pmc_traffic(kernel_substr: str, prefix: str, smallest_grid: bool = False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<prefix>_*.csv;
     the counters cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 reports half the bytes of a wide
     coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB.  The passes carry a sidecar
     profiles/<prefix>_source.json = {"files": [...], "sha": ...} written by tools/collect_profiles.sh with the hash of the
-    kernel sources they measured; if the sources changed since (or there is no sidecar) the figure is stale -> null."""
+    kernel sources they measured; if the sources changed since (or there is no sidecar) the figure is stale -> null.
+    ``smallest_grid``: the pass holds launches of that kernel on several shapes (the stride-2 probe calls the blur on 3B images);
+    the entry's launch is the one with the smallest grid."""
     import csv
     try:
         side = json.load(open(os.path.join(ROOT, "profiles", prefix + "_source.json")))
@@ -396,9 +398,12 @@ def _pmc_traffic(kernel_substr: str, prefix: str):
     try:
         vals = {}
         for name, fn in (("FETCH_SIZE", prefix + "_fetch_size.csv"), ("WRITE_SIZE", prefix + "_write_size.csv")):
-            rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn)))
+            rows = [(int(r["Grid_Size"]), float(r["Counter_Value"])) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn)))
                     if r["Counter_Name"] == name and kernel_substr in r["Kernel_Name"]]
-            vals[name] = sum(rows) / len(rows)
+            if smallest_grid:
+                g0 = min(g for g, _ in rows)
+                rows = [r for r in rows if r[0] == g0]
+            vals[name] = sum(v for _, v in rows) / len(rows)
         return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), \
             "profiles/%s_fetch_size.csv + %s_write_size.csv (separate --pmc passes; FETCH_SIZE x2)" % (prefix, prefix)
     except Exception:
