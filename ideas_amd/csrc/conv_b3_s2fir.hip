@@ -27,6 +27,14 @@
 #include "b3.hpp"
 #include <cstdlib>
 
+#ifndef S2FIR_XB_AUX
+// Cache policy of the side-output stores (A/B builds: -DS2FIR_XB_AUX=n; 0 = default, 1 = sc0, 2 = nt, 3 = sc0 nt).  A store
+// instruction covers 64 contiguous bytes of a pixel (16 channels), the other chunks of the pixel's line follow thousands of cycles
+// later: with the default policy the L2 fetches every partially written line (profiles/r04_pmc_b3s2: 5.29 GB fetched with the side
+// output against 3.71 without).  Non-temporal: Dreal.1.conv2 with the side output 3.45 -> 3.35-3.38 ms, the others 1-3 % (same box).
+#define S2FIR_XB_AUX 2
+#endif
+
 namespace {
 
 constexpr int TR = 8, TP = 16;                 // output patch
@@ -169,7 +177,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
                 //  follows the ISA manual's "no wait state needed" and overwrote the data registers in the very next instruction -- on
                 //  this part the second component of lanes 12-15 (mod 16) then stored the NEW value: tools/probes/dbg_xb.py)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rxb,
-                                                       (int)((xb_off + so) | (unsigned)__builtin_amdgcn_sbfe(rbad, 24, 1) | rowbad), 0, 0);   // masked: dropped
+                                                       (int)((xb_off + so) | (unsigned)__builtin_amdgcn_sbfe(rbad, 24, 1) | rowbad), 0, S2FIR_XB_AUX);   // masked: dropped
             }
         };
 
