@@ -315,3 +315,54 @@ def test_deferred_d_step_guards_discriminators_and_is_always_waited():
     waited.clear()
     TS.train_iteration(tr, args, X, 1, reducer=Reducer())          # the normal path still completes every exchange exactly once
     assert sorted(waited) == ["d", "ex"] and not TS._D_PENDING[0]
+
+
+def test_bench_evidence_readers_drop_stale_files(tmp_path, monkeypatch):
+    """bench.py quotes two kinds of committed measurements that it cannot take itself -- PMC traffic of the roofline kernels and the
+    stock-eager comparator -- and must drop either when it no longer describes the tree (evidence hygiene): the PMC rows
+    carry a hash of the kernel sources, the eager files a torch version / comparator source hash / batch sidecar.  Also: the entry's
+    own launch is picked when a pass holds several shapes or instantiations of the kernel."""
+    import csv
+    import hashlib
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (tmp_path / "ideas_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "ideas_amd" / "csrc" / "k.hip").write_text("kernel v1")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    sha = bench._src_sha(["k.hip"])
+    (prof / "rX_pmc_k_source.json").write_text(json.dumps({"files": ["k.hip"], "sha": sha}))
+    hdr = ["Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value"]
+    rows = [(1000, "void k<4, 4, 1, false>(float*)", 100.0), (1000, "void k<4, 4, 1, true>(float*)", 400.0), (3000, "void k<4, 4, 1, false>(float*)", 900.0)]
+    for cname, fn, mul in (("FETCH_SIZE", "rX_pmc_k_fetch_size.csv", 1.0), ("WRITE_SIZE", "rX_pmc_k_write_size.csv", 0.5)):
+        with open(prof / fn, "w", newline="") as fp:
+            w = csv.writer(fp)
+            w.writerow(hdr)
+            for g_, n_, v_ in rows:
+                w.writerow([g_, n_, cname, v_ * mul])
+    kb = lambda fetch, write: int((2 * fetch + write) * 1024)
+    assert bench._pmc_traffic("k<4, 4, 1, false>", "rX_pmc_k")[0] == kb(500.0, 250.0)                       # both grids of that instantiation
+    assert bench._pmc_traffic("k<4, 4, 1, false>", "rX_pmc_k", smallest_grid=True)[0] == kb(100.0, 50.0)    # the entry's own launch
+    assert bench._pmc_traffic("k<4, 4, 1, true>", "rX_pmc_k")[0] == kb(400.0, 200.0)
+    (tmp_path / "ideas_amd" / "csrc" / "k.hip").write_text("kernel v2")                                     # the kernel changed: stale
+    val, note = bench._pmc_traffic("k<4, 4, 1, false>", "rX_pmc_k")
+    assert val is None and "stale" in note
+
+    # eager comparator files: full (default find mode) preferred over fast; any sidecar mismatch drops the file
+    for f in ("oracle/torch_ref.py", "tests/eager_baseline.py"):
+        os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
+        (tmp_path / f).write_text("source of " + f)
+    src = b"".join(open(tmp_path / f, "rb").read() for f in ("oracle/torch_ref.py", "tests/eager_baseline.py"))
+    side = dict(torch_version=torch.__version__, source_sha16=hashlib.sha256(src).hexdigest()[:16], batch=32, convs="MIOpen", steps=3,
+                ms_per_step=1000.0)
+    a = argparse.Namespace(batch=32)
+    assert bench.eager_complete(a) is None
+    (prof / "r04_eager_fast.json").write_text(json.dumps(dict(side, eager_gpu_images_per_sec=16.0)))
+    assert bench.eager_complete(a)["eager_gpu_images_per_sec"] == 16.0
+    (prof / "r04_eager_full.json").write_text(json.dumps(dict(side, eager_gpu_images_per_sec=18.0)))
+    assert bench.eager_complete(a)["file"] == "profiles/r04_eager_full.json"
+    assert bench.eager_complete(argparse.Namespace(batch=16)) is None                                        # another batch
+    (prof / "r04_eager_full.json").write_text(json.dumps(dict(side, eager_gpu_images_per_sec=18.0, torch_version="0.0")))
+    assert bench.eager_complete(a)["file"] == "profiles/r04_eager_fast.json"                                 # stale full -> the fast one
+    (tmp_path / "oracle" / "torch_ref.py").write_text("the comparator's step changed")
+    assert bench.eager_complete(a) is None
