@@ -305,7 +305,7 @@ def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
 def roofline_probe_s2(device, batch: int, launches: int):
     """Stride-2 entry: Blur(pad (2,2)) -> 3x3 / stride-2 conv of Dreal.1.conv2 (128 -> 128 channels, 256x256 -> 128x128,
     on the 3B images of the discriminator's fake pass) as ONE kernel, conv_b3_s2fir_kernel (csrc/conv_b3_s2fir.hip); beside it the
-    two-kernel chain it replaces (blur4_f32_c2 + conv_b3_kernel) and the layer's weight gradient on the generic split kernel.
+    two-kernel chain it replaces (blur4_f32_c2 + conv_b3_kernel) and the layer's weight gradient (tap-fused stride-2 kernel).
     FLOPs: the convolution's only (the FIR's are not counted)."""
     from ideas_amd import _lib
     from ideas_amd.model import make_kernel
@@ -350,7 +350,8 @@ def roofline_probe_s2(device, batch: int, launches: int):
             "with_blurred_side_output": {"ms_per_launch": round(ms_fx, 4), "tflops": tf(ms_fx)},
             "two_kernel_chain": {"blur_ms": round(ms_blur, 4), "conv_ms": round(ms_conv, 4), "conv_tflops": tf(ms_conv),
                                  "chain_ms": round(ms_blur + ms_conv, 4), "chain_tflops": tf(ms_blur + ms_conv)},
-            "weight_gradient": {"kernel": "conv_b3_wgrad_kernel (generic split weight gradient, stride 2) on the blurred tensor",
+            "weight_gradient": {"kernel": ("conv_b3_wgrad_kernel (generic split weight gradient, stride 2)" if os.environ.get("IDEAS_B3_WGRAD3_S2", "1") == "0"
+                                           else "conv_b3_wgrad3_kernel<2,false,false> (tap-fused, one window row per barrier)") + " on the blurred tensor",
                                 "ms_per_launch": round(ms_wg, 4), "tflops": tf(ms_wg), "frac": round(tf(ms_wg) / peak, 4)}}
 
 

@@ -334,11 +334,13 @@ extern "C" int ideas_b3_wgrad3_supported(const ideas_conv_params* p) {
     if (p->TY != 3 || p->TX != 3 || p->dy != 1 || p->dx != 1 || p->sy != p->sx || (p->sy != 1 && p->sy != 2)) return 0;
     if (p->osy != 1 || p->osx != 1 || p->ooy != 0 || p->oox != 0 || p->YH != p->OH || p->YW != p->OW) return 0;
     if (p->OW % 16 || p->Cin % 64 || p->Cout % 64) return 0;
-    // stride 2 (the Blur -> 3x3/s2 convs, the upsampling modulated convs): correct (tests/test_ops_gpu.py) but measured 4-7 % SLOWER
-    // than conv_b3_wgrad.hip -- two window rows, i.e. two barriers, per output row with MFMAs in every other one -- so it is opt-in
+    // stride 2 (the Blur -> 3x3/s2 convs, the upsampling modulated convs): two window rows, i.e. two barriers, per output row with
+    // MFMAs in every other one.  Round 3 measured it 4-7 % SLOWER than conv_b3_wgrad.hip and kept it opt-in; with the address-free
+    // transpose reads of round 4 it is ahead: same box, two interleaved runs of 32 iterations, 412.34 / 412.42 -> 411.49 / 411.78 ms
+    // (tools/ab_step.sh).  IDEAS_B3_WGRAD3_S2=0 switches it off (A/B measurements).
     if (p->sy == 2) {
         static int s2 = -1;
-        if (s2 < 0) { const char* e = getenv("IDEAS_B3_WGRAD3_S2"); s2 = (e && e[0] == '1') ? 1 : 0; }
+        if (s2 < 0) { const char* e = getenv("IDEAS_B3_WGRAD3_S2"); s2 = (e && e[0] == '0') ? 0 : 1; }
         if (!s2) return 0;
     }
     if (p->reflect && (p->IH < 2 || p->IW < 2)) return 0;

@@ -23,7 +23,7 @@ def _ensure_built():
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
-os.environ.setdefault("IDEAS_B3_WGRAD3_S2", "1")      # the opt-in stride-2 path of csrc/conv_b3_wgrad3.hip is tested as well
+os.environ.setdefault("IDEAS_B3_WGRAD3_S2", "1")      # (the default since round 4: the stride-2 path of csrc/conv_b3_wgrad3.hip)
 
 
 def pytest_configure(config):

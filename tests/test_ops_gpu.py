@@ -966,7 +966,7 @@ def test_b3_tap_fused_weight_gradient(case):
     (gw_abs,) = torch.autograd.grad(fwd(x.abs(), wa), wa, gy.abs())          # sum |gy * x| per weight
     g = ConvGeom(3, 3, st, pd, refl)
     p = CV._params(plan_wgrad(x.shape, y.shape, g), gain)
-    # (stride 2 is opt-in -- IDEAS_B3_WGRAD3_S2=1, set by conftest for this module's process -- because it measured slower)
+    # (stride 2: the default since round 4, IDEAS_B3_WGRAD3_S2=0 switches it off)
     assert _lib.load().ideas_b3_wgrad3_supported(C.byref(p)) == 1, case
     xd, gyd = dev(x.float(), True), dev(gy.float(), True)
     sd = dev(s.float()) if scaled else None
