@@ -28,7 +28,7 @@ def _one(pre, name, grid, grows):
     print(f"   LDS bank conflict / idx active: {m.get('SQ_LDS_BANK_CONFLICT', 0):.3g} / {m.get('SQ_LDS_IDX_ACTIVE', 0):.3g}")
 
 
-for pre in ("b3w", "b3wg", "b3tp", "b3s2", "bf16", "bf16wg", "blurf32", "blurbf16"):
+for pre in ("b3w", "b3wg", "b3wg2", "b3tp", "b3s2", "bf16", "bf16wg", "blurf32", "blurbf16"):
     groups = collections.OrderedDict()          # one table entry per (kernel instantiation, grid): a pass may hold several shapes
     for cs in ("fetch_size", "write_size", "sq_wave", "sq_insts", "lds_grbm"):
         f = os.path.join(root, f"{rnd}_pmc_{pre}_{cs}.csv")

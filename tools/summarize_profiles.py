@@ -14,7 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, rnd = sys.argv[1], sys.argv[2]
 KERNEL = {"f32": "conv_b3_wino2d_kernel", "bf16": "conv_bf16_img_kernel"}
-WGRAD = {"f32": ("conv_b3_wgrad3_kernel", "b3wg"), "bf16": ("conv_bf16_wgrad3_kernel", "bf16wg")}      # bench.py's roofline_wgrad entry
+WGRAD = {"f32": ("conv_b3_wgrad3_kernel<1,", "b3wg"), "bf16": ("conv_bf16_wgrad3_kernel", "bf16wg")}     # bench.py's roofline_wgrad entry
+WGRAD2 = {"f32": ("conv_b3_wgrad3_kernel<2,", "b3wg2"), "bf16": (None, None)}   # the stride-2 instantiation (roofline_s2.weight_gradient)
 BLUR = {"f32": ("blur4_f32_c2", "blurf32"), "bf16": ("blur4_bf16x8_c2", "blurbf16")}                 # bench.py's roofline_hbm entry
 DIRECT = {"f32": ("conv_b3_tphase_kernel", "b3tp"), "bf16": (None, None)}                            # bench.py's roofline_direct entry
 S2 = {"f32": ("conv_b3_s2fir_kernel", "b3s2"), "bf16": (None, None)}                                 # bench.py's roofline_s2 entry
@@ -38,13 +39,16 @@ for tag, kern in KERNEL.items():
         bk, btag = BLUR[tag]
         dk, dtag = DIRECT[tag]
         sk, stag = S2[tag]
+        w2k, w2tag = WGRAD2[tag]
         for kname, prefix in ((kern, pre), (wk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{wtag}")),
+                              (w2k, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{w2tag}")),
                               (bk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{btag}")),
                               (dk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{dtag}")),
                               (sk, os.path.join(ROOT, "profiles", f"{rnd}_pmc_{stag}"))):
             if kname is None:
                 continue
-            keep = [r for r in rows if kname + "<" in r["Kernel_Name"] or kname + "(" in r["Kernel_Name"]]
+            keep = [r for r in rows if (kname in r["Kernel_Name"].replace(", ", ",") if "<" in kname else
+                                        kname + "<" in r["Kernel_Name"] or kname + "(" in r["Kernel_Name"])]
             if keep:
                 with open(prefix + "_" + short + ".csv", "w", newline="") as fp:
                     w = csv.DictWriter(fp, fieldnames=list(keep[0].keys()), quoting=csv.QUOTE_ALL)
