@@ -143,6 +143,17 @@ def test_tiny_spatial_weight_gradient_vs_f64(monkeypatch, case, gemm):
                             None if lin is None else lin.cuda(), None if lout is None else lout.cuda(), out=out)
     assert got.dtype == torch.float32
     assert rel_err(got - 0.5, ref) < (2e-3 if mod else 2e-5), (case, gemm, rel_err(got - 0.5, ref))
+    if mod and not gemm:
+        # the same layer WITHOUT the pre-scaling of small modulated images (op/conv.py): the kernel applies the per-sample scales to
+        # its accumulators, one sample per split -- the form a C-ABI caller gets from ideas_conv_wgrad(IDEAS_BF16) with scales.  The
+        # operands are then rounded before the scaling, not after: compare against f64 on the UNSCALED rounded operands.
+        monkeypatch.setattr(CV, "PRESCALE_MOD_PIX", 0)
+        w2 = torch.zeros(co, ci, k, k, dtype=torch.float64, requires_grad=True)
+        ref2, = torch.autograd.grad(F.conv2d(x * lin.double()[:, :, None, None], w2, stride=st, padding=pad) * gain, w2,
+                                    gy * lout.double()[:, :, None, None])
+        out2 = torch.zeros((co, ci, k, k), device="cuda").contiguous(memory_format=CL)
+        got2 = CV.conv_wgrad_raw(dev(gy, dtype=BF), dev(x, dtype=BF), g, (co, ci, k, k), gain, lin.cuda(), lout.cuda(), out=out2)
+        assert rel_err(got2, ref2) < 2e-5, (case, "in-kernel scales", rel_err(got2, ref2))
 
 
 def test_bf16_image_and_tap_fused_kernels_full_size(monkeypatch):
