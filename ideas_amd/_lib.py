@@ -57,6 +57,8 @@ _PROTOS = {
     "ideas_abi_version": (C.c_int, []),
     "ideas_sizeof_conv_params": (C.c_int, []),
     "ideas_strerror": (C.c_char_p, [C.c_int]),
+    "ideas_stream_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "ideas_stream_destroy": (C.c_int, [_P]),
     "ideas_fused_bias_act": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_float, C.c_int, _P]),
     "ideas_upfirdn2d": (C.c_int, [_P, _P, _P] + [C.c_int] * 14 + [C.c_float, C.c_int, C.c_int, C.c_int, _P]),
@@ -144,6 +146,14 @@ def stream_ptr() -> int:
     # the raw handle of the current stream of the current device, without building a torch.cuda.Stream object (9.5 us a call,
     # 940 calls per iteration: 9 ms of host time of a 190 ms bf16 step -- tools/host_profile.py)
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def make_stream(prio: int) -> "torch.cuda.Stream":
+    """A torch view of a HIP stream of the lowest (prio < 0) / default (0) / highest (> 0) priority (ideas_stream_create): torch's own
+    pools only offer default and higher."""
+    h = C.c_void_p()
+    check(load().ideas_stream_create(C.byref(h), int(prio)), "ideas_stream_create")
+    return torch.cuda.ExternalStream(h.value)
 
 
 def require_cuda(*tensors: Optional[torch.Tensor]) -> None:

@@ -18,6 +18,27 @@ extern "C" const char* ideas_strerror(int code) {
     return "unknown ideas_hip error";
 }
 
+// A HIP stream of the lowest (prio < 0), default (0) or highest (prio > 0) priority the device offers.  The gradient sink
+// (ideas_amd/op/conv.py) runs the weight-gradient kernels on a LOW-priority stream: they are throughput work that should fill what
+// the critical path (the input-gradient chain on the caller's stream) leaves free, not compete with it block for block -- with
+// equal priorities a 20-us elementwise launch of the main stream waited up to 2 ms for a CU behind a weight-gradient grid.
+extern "C" int ideas_stream_create(void** out, int prio) {
+    if (!out) return IDEAS_E_NULL;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio < 0 ? least : prio > 0 ? greatest : 0);
+    if (e != hipSuccess) return (int)e;
+    *out = (void*)s;
+    return IDEAS_OK;
+}
+
+extern "C" int ideas_stream_destroy(void* stream) {
+    if (!stream) return IDEAS_E_NULL;
+    return (int)hipStreamDestroy((hipStream_t)stream);
+}
+
 extern "C" int ideas_sizeof_prep_desc(void) { return (int)sizeof(ideas_prep_desc); }
 
 extern "C" int ideas_weight_prep_batched(const ideas_prep_desc* table, int n, int op, int total_blocks, void* stream) {

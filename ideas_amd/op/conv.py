@@ -482,6 +482,11 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
 # a Function cannot see the ``inputs=`` filter of ``torch.autograd.backward``.
 # ----------------------------------------------------------------------------------------------------
 _SINK = {"ids": None, "stream": None}
+# IDEAS_SINK_PRIORITY=low puts the side stream on the device's LOWEST priority (ideas_stream_create).  Measured round 5, same box,
+# interleaved: f32 412.2 -> 413.6 ms, bf16 154.7 -> 154.2 ms (noise) -- and the same with the whole iteration on a highest-priority
+# stream (414.2 ms).  A kernel trace shows 20-us torch adds of the main stream taking up to 1.9 ms next to a weight-gradient grid, but
+# the chip is busy throughout: the queue priority changes who waits, not how much work the compute units retire.  Default: off.
+SINK_LOW_PRIORITY = _os.environ.get("IDEAS_SINK_PRIORITY", "default") == "low"
 
 
 class grad_sink:
@@ -492,7 +497,7 @@ class grad_sink:
         if not self.ids:            # nothing to sink (no pre-existing device gradients): plain autograd
             return self
         if _SINK["stream"] is None:
-            _SINK["stream"] = torch.cuda.Stream()
+            _SINK["stream"] = _lib.make_stream(-1) if SINK_LOW_PRIORITY else torch.cuda.Stream()
         _SINK["ids"] = self.ids
         return self
 

@@ -55,6 +55,13 @@ int ideas_abi_version(void);
 int ideas_sizeof_conv_params(void);   /* lets a binding check its mirror of ideas_conv_params */
 const char* ideas_strerror(int code);
 
+/* Stream helper (no reference counterpart: the reference runs everything on torch's current stream).  Creates a non-blocking HIP
+ * stream of the lowest (prio < 0), default (prio == 0) or highest (prio > 0) priority of the device; the caller owns it
+ * (ideas_stream_destroy).  The host side runs the weight-gradient kernels on a lowest-priority stream so that they fill what the
+ * input-gradient chain on the caller's stream leaves free instead of competing with it for compute units. */
+int ideas_stream_create(void** out_stream, int prio);
+int ideas_stream_destroy(void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * fused bias + leaky-ReLU.  Replaces fused_bias_act_op (fused_bias_act_kernel.cu:52-98).
  *
