@@ -25,6 +25,9 @@
 // (conv_b3_wgrad.hip reads it as before).  Measurements, the ablations behind this shape and what the fusion can and cannot buy:
 // DESIGN.md section 3.9.
 #include "b3.hpp"
+#ifndef S2FIR_DPP_BUILTIN
+#define S2FIR_DPP_BUILTIN 0
+#endif
 #include <cstdlib>
 
 #ifndef S2FIR_XB_AUX
@@ -134,17 +137,28 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
         };
         // The three shifted taps are v_fmac_f32 with a DPP source (row_shl:n = the lane n columns to the right, 0 past the 16-lane
         // row).  Written in assembly: hipcc keeps __builtin_amdgcn_update_dpp as a separate v_mov_b32_dpp per shift (240 per chunk;
-        // its FMAs are the VOP3 / packed forms, which take no DPP operand).  v_fmac needs the tap in a VGPR.  (s_nop 1: a VALU
-        // write of the source followed by a DPP read wants two wait states, and the hazard recogniser does not look inside asm.)
+        // its FMAs are the VOP3 / packed forms, which take no DPP operand).  v_fmac needs the tap in a VGPR.  The hazard recogniser
+        // does not look inside asm, so the wait states are ours: a VALU write of the DPP source wants 2, a VALU write of EXEC 5 --
+        // s_nop 4 (five states) covers whatever the compiler schedules in front (s_nop 1 was enough for what it
+        // schedules today).  All 64 lanes are active here (no divergent code around the producer loop).
+        // -DS2FIR_DPP_BUILTIN=1 builds the same arithmetic from __builtin_amdgcn_update_dpp + fmaf (the compiler then owns the
+        // hazards): libideas_hip_dppb.so of the Makefile, which tests/test_ops_gpu.py runs through the same bitwise checks.
         float kh1 = f.kh[1], kh2 = f.kh[2], kh3 = f.kh[3];
         asm volatile("" : "+v"(kh1), "+v"(kh2), "+v"(kh3));
         auto hrow1 = [&](float v) {                      // blur4_f32_c2::hrow: fma chain over the four columns, from zero
             float a = fmaf(v, f.kh[0], 0.f);
-            asm volatile("s_nop 1\n\t"
+#if S2FIR_DPP_BUILTIN
+            const int vi = __builtin_bit_cast(int, v);
+            a = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x101, 0xf, 0xf, true)), kh1, a);
+            a = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x102, 0xf, 0xf, true)), kh2, a);
+            a = fmaf(__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x103, 0xf, 0xf, true)), kh3, a);
+#else
+            asm volatile("s_nop 4\n\t"
                          "v_fmac_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                          "v_fmac_f32_dpp %0, %1, %3 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                          "v_fmac_f32_dpp %0, %1, %4 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
                          : "+v"(a) : "v"(v), "v"(kh1), "v"(kh2), "v"(kh3));
+#endif
             return a;
         };
         auto hrow = [&](int r) {
@@ -367,8 +381,8 @@ extern "C" int ideas_b3_blur_conv_s2(void* y, void* xb_out, const void* x, const
     f.XH = xh; f.XW = xw; f.pad0 = pad0;
     hipStream_t stream = (hipStream_t)stream_;
     // IDEAS_S2FIR_CFG (A/B measurements): 0 = default, 1 = eight consumer waves everywhere, 2 = four everywhere
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("IDEAS_S2FIR_CFG"); cfg = e ? atoi(e) : 0; }
+    const char* ecfg = getenv("IDEAS_S2FIR_CFG");       // (read per call: no state in the library, include/ideas_hip.h)
+    const int cfg = ecfg ? atoi(ecfg) : 0;
     const bool eight = cfg == 1 || (cfg == 0 && p->Cout > 128);
     // a consumer wave = all 128 pixels x 32 channels (every weight fragment is loaded by exactly one wave)
     if (p->Cout > 128 && eight) return launch_s2fir<8, 8, 1>(y, xb_out, x, wplanes, bias, resid, p, f, stream);   // N tile 256

@@ -321,12 +321,8 @@ int launch_wgrad3(float* gw, const void* gy, const void* x, const float* in_scal
 }  // namespace
 
 bool ideas_b3_wgrad3_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("IDEAS_B3_WGRAD3");
-        on = !(e && e[0] == '0');
-    }
-    return on != 0;
+    const char* e = getenv("IDEAS_B3_WGRAD3");          // (read per call: no state in the library, include/ideas_hip.h)
+    return !(e && e[0] == '0');
 }
 
 extern "C" int ideas_b3_wgrad3_supported(const ideas_conv_params* p) {
@@ -339,9 +335,8 @@ extern "C" int ideas_b3_wgrad3_supported(const ideas_conv_params* p) {
     // transpose reads of round 4 it is ahead: same box, two interleaved runs of 32 iterations, 412.34 / 412.42 -> 411.49 / 411.78 ms
     // (tools/ab_step.sh).  IDEAS_B3_WGRAD3_S2=0 switches it off (A/B measurements).
     if (p->sy == 2) {
-        static int s2 = -1;
-        if (s2 < 0) { const char* e = getenv("IDEAS_B3_WGRAD3_S2"); s2 = (e && e[0] == '0') ? 0 : 1; }
-        if (!s2) return 0;
+        const char* e = getenv("IDEAS_B3_WGRAD3_S2");
+        if (e && e[0] == '0') return 0;
     }
     if (p->reflect && (p->IH < 2 || p->IW < 2)) return 0;
     // every window pixel the taps can address must lie inside what one strip stages: ix = ox*S + tx + offx, tx in 0..2

@@ -251,10 +251,21 @@ class ResBlock(nn.Module):
         return m1[0], m1[1], refl, m2[0], m2[1], m2[2]
 
     def _body_pair_ok(self, x) -> bool:
+        """down_pair_ok for this block, memoised per (input shape / dtype, grad mode, conv2 trainable, activation dtype, the module
+        switches of op.conv): the decision builds a launch plan and asks the library (ctypes), which the step would otherwise repeat
+        in every forward -- also for the blocks that can never fuse."""
+        from .op import conv as _cv
+        from .precision import activation_dtype
         c1, a1, refl, blur, c2, a2 = self._fused
-        if a1.negative_slope != a2.negative_slope:
-            return False
-        return down_pair_ok(x, c1.weight, c2.weight, blur.kernel, blur.pad, refl if refl else c1.padding)
+        key = (tuple(x.shape), x.dtype, torch.is_grad_enabled(), c2.weight.requires_grad, activation_dtype(), _cv.BLUR_CONV,
+               _cv.BLUR_CONV_MIN_BLOCKS, _cv.BLUR_CONV_MIN_OW, _cv.MATH)
+        memo = self.__dict__.setdefault("_pair_ok_memo", {})
+        hit = memo.get(key)
+        if hit is None:
+            hit = (a1.negative_slope == a2.negative_slope and a1.bias is not None and a2.bias is not None
+                   and down_pair_ok(x, c1.weight, c2.weight, blur.kernel, blur.pad, refl if refl else c1.padding))
+            memo[key] = hit
+        return hit
 
     def _body_pair(self, x, post_gain: float = 1.0, resid=None):
         c1, a1, refl, blur, c2, a2 = self._fused

@@ -749,7 +749,8 @@ class _ConvBiasAct(Function):
         if tgt is not None:          # gradient sink: bias gradient accumulated by the kernel into bias.grad
             g_pre, gb = bias_act_raw(gy, None, y, 1, ctx.slope, ctx.act_gain, bias_grad_into=tgt)
         else:
-            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(gy, y, ctx.slope, ctx.act_gain, True)
+            # (a frozen layer -- the discriminators in the G phase -- needs no bias gradient: no zero-fill, no reduction in the kernel)
+            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(gy, y, ctx.slope, ctx.act_gain, bool(ctx.needs_input_grad[2]))
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(g_pre, w, ctx.g, ctx.gain, (x.shape[2], x.shape[3]))
@@ -787,7 +788,7 @@ class _ConvBiasActBlur(Function):
         gb = None
         if torch.is_grad_enabled() or not blur_fused_ok(y1, fir):
             g1 = UpFirDn2dBackward.apply(gyb, fir, (1, 1), (1, 1), ctx.pad4, ctx.g_pad, tuple(y1.shape), ctx.out_hw)
-            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(g1, y1, ctx.slope, ctx.act_gain, True)
+            g_pre, gb = FusedLeakyReLUFunctionBackward.apply(g1, y1, ctx.slope, ctx.act_gain, bool(need_b))
         else:
             tgt = bias_sink(ctx.bias_ref) if need_b else None
             if tgt is None:
@@ -921,7 +922,7 @@ class _DownPair(Function):
         if tgt2 is not None:
             g_pre2, _ = bias_act_raw(gy2, None, y2, 1, ctx.slope2, ctx.ag2, bias_grad_into=tgt2)
         else:
-            g_pre2, gb2 = FusedLeakyReLUFunctionBackward.apply(gy2, y2, ctx.slope2, ctx.ag2, True)
+            g_pre2, gb2 = FusedLeakyReLUFunctionBackward.apply(gy2, y2, ctx.slope2, ctx.ag2, bool(need[4]))
         gw2 = None
         if need[3]:
             if yb is None:      # (cannot happen: w2 required a gradient in the forward, so the side output was written)
@@ -930,7 +931,7 @@ class _DownPair(Function):
         gyb = _ConvDgrad.apply(g_pre2, w2, g2, ctx.gain2, ctx.out_hw)
         if torch.is_grad_enabled() or not blur_fused_ok(y1, fir):
             g1 = UpFirDn2dBackward.apply(gyb, fir, (1, 1), (1, 1), ctx.pad4, ctx.g_pad, tuple(y1.shape), ctx.out_hw)
-            g_pre1, gb1 = FusedLeakyReLUFunctionBackward.apply(g1, y1, ctx.slope1, ctx.ag1, True)
+            g_pre1, gb1 = FusedLeakyReLUFunctionBackward.apply(g1, y1, ctx.slope1, ctx.ag1, bool(need[2]))
         else:
             tgt1 = bias_sink(ctx.b1_ref) if need[2] else None
             if tgt1 is None:

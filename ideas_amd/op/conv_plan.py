@@ -246,9 +246,35 @@ def cached(w: torch.Tensor, key, make, prep=None):
     return v
 
 
-# Byte budget of the per-sample bf16 weight packs memoised by cached_on(..., budget=True): tens to hundreds of MB each at B = 32
-STYLE_BUDGET_MB = int(_os.environ.get("IDEAS_STYLE_BUDGET_MB", "1536"))
-_BUDGETED = {}      # cache key -> bytes, in insertion order
+# Byte budget of the per-sample bf16 weight packs memoised by cached_on(..., budget=True): tens to hundreds of MB each at B = 32.
+# G's layers are visited cyclically (forward packs of layers 1..16, again for the next pass over the same styles, then the input
+# gradients' packs), so an evicting policy -- FIFO or LRU alike -- drops exactly the entries the next pass asks for once the working
+# set exceeds the budget.  Admission control instead: entries are admitted until the budget is full and then stay for
+# the iteration (hit rate = budget / working set, never zero); a miss beyond the budget is made, used and dropped by its caller.
+# B = 32 at 256x256: 1.2 GB of forward packs + 1.2 GB of input-gradient packs per recurring style (T1), the same again for T2 of the
+# G phase -> 4 GB keeps both (of 288 GB); BUDGET_STATS counts what happened (tools/probes/pack_cache_stats.py).
+STYLE_BUDGET_MB = int(_os.environ.get("IDEAS_STYLE_BUDGET_MB", "4096"))
+_BUDGETED = {}      # cache key -> bytes of the admitted entries still in _CACHE
+_BUDGET_TOTAL = [0]
+BUDGET_STATS = {"hit": 0, "admitted": 0, "rejected": 0, "peak_bytes": 0}
+
+
+def _budget_admit(k, nbytes: int) -> bool:
+    def sweep():                             # cache_clear / a new iteration drop entries behind our back
+        for dead in [q for q in _BUDGETED if q not in _CACHE]:
+            _BUDGET_TOTAL[0] -= _BUDGETED.pop(dead)
+    if len(_BUDGETED) and next(iter(_BUDGETED)) not in _CACHE:
+        sweep()
+    if _BUDGET_TOTAL[0] + nbytes > STYLE_BUDGET_MB << 20:
+        sweep()
+    if _BUDGET_TOTAL[0] + nbytes > STYLE_BUDGET_MB << 20:
+        BUDGET_STATS["rejected"] += 1
+        return False
+    _BUDGETED[k] = nbytes
+    _BUDGET_TOTAL[0] += nbytes
+    BUDGET_STATS["admitted"] += 1
+    BUDGET_STATS["peak_bytes"] = max(BUDGET_STATS["peak_bytes"], _BUDGET_TOTAL[0])
+    return True
 
 
 def cached_on(w: torch.Tensor, key, t: torch.Tensor, make, budget: bool = False):
@@ -266,17 +292,11 @@ def cached_on(w: torch.Tensor, key, t: torch.Tensor, make, budget: bool = False)
     v = _CACHE.get(k)
     if v is None:
         v = (t, make())
+        if budget and torch.is_tensor(v[1]) and not _budget_admit(k, v[1].numel() * v[1].element_size()):
+            return v[1]                      # over budget: used once by the caller, not kept
         _CACHE[k] = v
-        if budget and torch.is_tensor(v[1]):
-            for dead in [q for q in _BUDGETED if q not in _CACHE]:      # (dropped by cache_clear / a new iteration)
-                del _BUDGETED[dead]
-            _BUDGETED[k] = v[1].numel() * v[1].element_size()
-            total = sum(_BUDGETED.values())
-            for old in list(_BUDGETED):
-                if total <= STYLE_BUDGET_MB << 20 or old == k:
-                    break
-                total -= _BUDGETED.pop(old)
-                _CACHE.pop(old, None)
+    elif budget:
+        BUDGET_STATS["hit"] += 1
     return v[1]
 
 

@@ -155,9 +155,9 @@ class FusedLeakyReLUFunction(Function):
         if tgt is not None:          # gradient sink: the kernel adds the bias gradient straight into bias.grad
             grad_input, _ = bias_act_raw(grad_output, None, out, 1, ctx.negative_slope, ctx.scale, bias_grad_into=tgt)
             return grad_input, None, None, None
-        grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale,
-                                                                      ctx.has_bias)
-        return grad_input, (grad_bias if ctx.has_bias else None), None, None
+        need_b = ctx.has_bias and ctx.needs_input_grad[1]        # a frozen bias: no zero-fill, no reduction in the kernel
+        grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale, bool(need_b))
+        return grad_input, (grad_bias if need_b else None), None, None
 
 
 def fused_leaky_relu(input: torch.Tensor, bias: Optional[torch.Tensor], negative_slope: float = 0.2,

@@ -169,16 +169,16 @@ class DeferredStepError(RuntimeError):
     pass
 
 
-_D_PENDING = [False]      # the D group's optimiser step is deferred: no discriminator may run (it would read pre-step weights)
-
-
 def _guard_discriminators(trainer) -> None:
-    """Once per trainer: forward pre-hooks on the discriminators that refuse to run while their optimiser step is deferred."""
+    """Once per trainer: forward pre-hooks on the discriminators that refuse to run while THIS trainer's D-group optimiser step is
+    deferred (the flag lives on the trainer -- ``trainer['_d_pending']`` -- so another trainer, an evaluation or a sampling pass in
+    the same process is not affected)."""
     if trainer.get("_d_guard"):
         return
+    trainer["_d_pending"] = False
 
     def pre(module, inputs):
-        if _D_PENDING[0]:
+        if trainer.get("_d_pending"):
             raise DeferredStepError(f"{type(module).__name__} called while the D group's optimiser step is deferred: it would run on "
                                     "pre-step weights (train_step._Deferred: finish() must come first)")
     for n in D_SIDE:
@@ -197,7 +197,13 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     T = trainer
     _guard_discriminators(T)
     if pending_list is None:
-        pending_list = []
+        # called directly (not through train_iteration): the clean-up of a deferred exchange an exception leaves behind happens here
+        own: list = []
+        try:
+            return _train_iteration(trainer, args, X, iter_idx, draws, reducer, hook, own)
+        finally:
+            for d in own:
+                d.abandon()
     if draws is None:
         draws = draw_step(args, X.shape[0], X.shape[-1], X.device)
     losses: Dict[str, torch.Tensor] = {}
@@ -222,12 +228,12 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
             self.done = False
             pending_list.append(self)
             if tag == "d":
-                _D_PENDING[0] = True      # nothing may run a discriminator until finish() (checked by their forward pre-hooks)
+                T["_d_pending"] = True    # nothing may run a discriminator until finish() (checked by their forward pre-hooks)
 
         def _release(self):
             self.done = True
             if self.tag == "d":
-                _D_PENDING[0] = False
+                T["_d_pending"] = False
             if self in pending_list:
                 pending_list.remove(self)
 

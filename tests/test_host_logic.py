@@ -298,7 +298,7 @@ def test_deferred_d_step_guards_discriminators_and_is_always_waited():
         def forward(self, *a, **k):
             calls["n"] += 1
             if calls["n"] == 4:          # the first G call of the G phase: inside the window of the deferred D step
-                assert TS._D_PENDING[0]
+                assert tr["_d_pending"]
                 with pytest.raises(TS.DeferredStepError):
                     tr["Ddist"](torch.zeros(1, 64))
                 raise ValueError("boom")
@@ -310,11 +310,30 @@ def test_deferred_d_step_guards_discriminators_and_is_always_waited():
     X = torch.rand(1, 3, 64, 64) * 2 - 1
     with pytest.raises(ValueError, match="boom"):
         TS.train_iteration(tr, args, X, 1, reducer=Reducer())
-    assert waited == ["d"] and not TS._D_PENDING[0]
+    assert waited == ["d"] and not tr["_d_pending"]
     tr["G"] = real_g
     waited.clear()
     TS.train_iteration(tr, args, X, 1, reducer=Reducer())          # the normal path still completes every exchange exactly once
-    assert sorted(waited) == ["d", "ex"] and not TS._D_PENDING[0]
+    assert sorted(waited) == ["d", "ex"] and not tr["_d_pending"]
+    # the flag is per trainer, and a DIRECT _train_iteration call that raises cleans up after itself -- a second trainer's
+    # (or an evaluation's) discriminators keep working in the same process
+    tr["G"] = Boom()
+    calls["n"] = 0
+    waited.clear()
+    with pytest.raises(ValueError, match="boom"):
+        TS._train_iteration(tr, args, X, 1, reducer=Reducer())
+    assert waited == ["d"] and not tr["_d_pending"]
+    tr["G"] = real_g
+    torch.manual_seed(6)
+    other = _oracle_trainer(TS.build_trainer(args, "cpu", init_model, dco_factory=ZeroDco), args)
+    TS._guard_discriminators(other)
+    tr["_d_pending"] = True
+    try:
+        other["Ddist"](torch.zeros(1, 64))                          # not this trainer's deferred step: runs
+        with pytest.raises(TS.DeferredStepError):
+            tr["Ddist"](torch.zeros(1, 64))
+    finally:
+        tr["_d_pending"] = False
 
 
 def test_bench_evidence_readers_drop_stale_files(tmp_path, monkeypatch):
@@ -366,3 +385,21 @@ def test_bench_evidence_readers_drop_stale_files(tmp_path, monkeypatch):
     assert bench.eager_complete(a)["file"] == "profiles/r04_eager_fast.json"                                 # stale full -> the fast one
     (tmp_path / "oracle" / "torch_ref.py").write_text("the comparator's step changed")
     assert bench.eager_complete(a) is None
+
+
+def test_conv_bias_call_sites_are_the_rgb_head_only():
+    """op.conv._AddBias adds the f32 bias parameter to the conv output under torch's type promotion, so in bf16 mode a conv
+    with a conv bias and no activation returns f32.  That is intended for G's RGB head (the image leaves G in f32 with one rounding)
+    and is only acceptable if no other layer of the seven networks takes that path: a ConvLayer gets a conv bias only with
+    ``bias and not activate`` (models.py:54-56 of the reference), which in IDEAS is G.to_rgb alone (models.py:294)."""
+    from ideas_amd import train_step as TS
+    from ideas_amd.model import EqualConv2d
+    from ideas_amd.models import EqualConvTranspose2d, init_model
+    args = TS.default_args(channel=4, texture_channel=64, channel_multiplier=0.125, image_size=256)
+    sites = []
+    for tag, cls in TS.NET_CLASSES.items():
+        net = init_model(cls, args)
+        for name, m in net.named_modules():
+            if isinstance(m, (EqualConv2d, EqualConvTranspose2d)) and m.bias is not None:
+                sites.append(f"{tag}.{name}")
+    assert sites == ["G.to_rgb.0"], sites

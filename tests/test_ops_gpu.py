@@ -1448,6 +1448,23 @@ def test_blur_conv_s2_vs_oracle(case):
         assert rel_err(yd, y2) < 2e-6
 
 
+def test_blur_conv_s2_dpp_builtin_build_is_bitwise_too():
+    """the producer's horizontal taps are hand-written v_fmac_f32_dpp assembly whose wait states the compiler's hazard
+    recogniser cannot see.  csrc/Makefile also builds libideas_hip_dppb.so with those taps from __builtin_amdgcn_update_dpp + fmaf
+    (-DS2FIR_DPP_BUILTIN=1: the compiler owns the hazards); the cases above -- f64 oracle, and the blurred side output BITWISE the
+    stand-alone blur kernel -- must hold for that build as well (child process: the library is chosen at import)."""
+    import os, subprocess, sys
+    from ideas_amd import _lib
+    lib = os.path.join(os.path.dirname(os.path.abspath(_lib.LIB_PATH)), "libideas_hip_dppb.so")
+    assert os.path.exists(lib), "make -C ideas_amd/csrc builds libideas_hip_dppb.so next to libideas_hip.so"
+    env = dict(os.environ, IDEAS_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_blur_conv_s2_vs_oracle"], env=env, capture_output=True, text=True, timeout=1200,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "%d passed" % len(BLUR_CONV_CASES) in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 64, "zero"), (1, 16, 128, 32, 48, "reflect"), (2, 64, 256, 32, 32, "zero"), (1, 16, 32, 16, 32, "zero")])
 @pytest.mark.parametrize("freeze2", [False, True])
 def test_down_pair_gradients_vs_oracle(case, freeze2, monkeypatch):
