@@ -52,6 +52,16 @@ class PrepDesc(C.Structure):
 
 PREP_B3_SPLIT, PREP_B3_WINO, PREP_BF16_PACK = 0, 1, 2
 
+
+class LinearSeg(C.Structure):
+    """Mirror of ``ideas_linear_seg`` (include/ideas_hip.h): one layer of a batched EqualLinear launch."""
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p),
+                ("n", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("ldgw", C.c_int), ("scale", C.c_float), ("bias_mul", C.c_float),
+                ("tile0", C.c_int), ("pad_", C.c_int)]
+
+
+LINEAR_MAX_SEGMENTS = 32
+
 _P = C.c_void_p
 _PROTOS = {
     "ideas_abi_version": (C.c_int, []),
@@ -103,6 +113,11 @@ _PROTOS = {
     "ideas_patch_resize_bwd": (C.c_int, [_P, _P, C.POINTER(C.c_int)] + [C.c_int] * 9 + [_P]),
     "ideas_sizeof_prep_desc": (C.c_int, []),
     "ideas_weight_prep_batched": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_sizeof_linear_seg": (C.c_int, []),
+    "ideas_linear_fwd": (C.c_int, [C.POINTER(LinearSeg), C.c_int, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ideas_linear_bwd_x_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "ideas_linear_bwd_x": (C.c_int, [C.POINTER(LinearSeg), C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
+    "ideas_linear_bwd_w": (C.c_int, [C.POINTER(LinearSeg), C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ideas_act_bwd_dot": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
 }
 EXPORTS = tuple(_PROTOS)
@@ -128,6 +143,8 @@ def load() -> C.CDLL:
         raise RuntimeError("libideas_hip.so ABI mismatch (version or ideas_conv_params layout)")
     if lib.ideas_sizeof_prep_desc() != C.sizeof(PrepDesc):
         raise RuntimeError("libideas_hip.so ABI mismatch (ideas_prep_desc layout)")
+    if lib.ideas_sizeof_linear_seg() != C.sizeof(LinearSeg):
+        raise RuntimeError("libideas_hip.so ABI mismatch (ideas_linear_seg layout)")
     _lib = lib
     return lib
 

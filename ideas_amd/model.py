@@ -11,6 +11,7 @@ kernel epilogue, no per-sample weight tensors.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -87,6 +88,9 @@ class EqualConv2d(nn.Module):
         return f"{self.__class__.__name__}({i}, {o}, {k}, stride={self.stride}, padding={self.padding})"
 
 
+BATCH_STYLES = os.environ.get("IDEAS_BATCH_STYLES", "1") != "0"     # 0: one modulation GEMM per layer (A/B measurements)
+
+
 class EqualLinear(nn.Module):
     """Linear with equalised learning rate; optional fused bias + leaky-ReLU."""
 
@@ -102,10 +106,10 @@ class EqualLinear(nn.Module):
         # scale * (x @ W^T) instead of x @ (W * scale)^T (stylegan2/model.py:152-160): the same product with the equalised-lr scale
         # in the GEMM's alpha — no scaled copy of the [out, in] weight, forward or backward (op/linear.py)
         x = input if input.dtype == torch.float32 else input.float()       # linear layers are f32 in every mode
-        b = self.bias if (self.bias is None or self.lr_mul == 1) else self.bias * self.lr_mul
         if self.activation:
+            b = self.bias if (self.bias is None or self.lr_mul == 1) else self.bias * self.lr_mul
             return fused_leaky_relu(equal_linear(x, self.weight, None, self.scale), b)
-        return equal_linear(x, self.weight, b, self.scale)
+        return equal_linear(x, self.weight, self.bias, self.scale, bias_mul=float(self.lr_mul))
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
@@ -172,6 +176,9 @@ class ModulatedConv2d(nn.Module):
         existing grad-mode entry are reused (detached); two grad-mode applications share ONE modulation node, whose gradient is
         then the sum of both (what autograd computes for a tensor used twice)."""
         from .op import conv_plan
+        pre = self.__dict__.get("_pre_style")
+        if pre is not None and pre[0] is style:          # computed by the generator for all its layers at once (styles_for)
+            return pre[1]
         w = self.modulation.weight
         if torch.is_grad_enabled():
             return conv_plan.cached_on(w, ("style", 1), style, lambda: self.modulation(style))
@@ -183,6 +190,47 @@ class ModulatedConv2d(nn.Module):
     def __repr__(self):
         return (f"{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
                 f"upsample={self.upsample}, downsample={self.downsample})")
+
+
+class styles_for:
+    """``with styles_for(convs, texture):`` -- s_l = modulation_l(texture) of ALL the ModulatedConv2d ``convs`` with one launch
+    (op.linear.multi_linear: the sixteen modulation layers of the generator read the same texture code, stylegan2/model.py:239) and
+    handed to each layer's ``_styles`` for the duration of the block.  One autograd node owns the sixteen layers, so the backward is
+    three launches (sum of the input gradients, all weight + bias gradients) instead of 16 x (two GEMMs, a sum, an add) + 15 adds.
+    Memoised per (modulation weights, texture tensor) like the per-layer styles; inactive under the modulated conv's second-order
+    composite form (path-length regulariser), whose per-layer path stays as it was."""
+
+    def __init__(self, convs, style):
+        self.convs, self.style = list(convs), style
+
+    def _make(self):
+        from .op.linear import multi_linear
+        return multi_linear(self.style, [(c.modulation.weight, c.modulation.bias, c.modulation.scale, float(c.modulation.lr_mul))
+                                         for c in self.convs])
+
+    def __enter__(self):
+        from .op import conv_plan
+        from .op.modulated_conv import _SECOND_ORDER
+        self.set = False
+        style = self.style
+        if (not self.convs or _SECOND_ORDER[0] or not BATCH_STYLES or not style.is_cuda
+                or any(c.modulation.activation or c.modulation.weight.shape[1] != style.shape[-1] for c in self.convs)):
+            return self
+        w0 = self.convs[0].modulation.weight
+        if torch.is_grad_enabled():
+            tup = conv_plan.cached_on(w0, ("styles", 1), style, self._make)
+        else:
+            hit = conv_plan.peek_on(w0, ("styles", 1), style)
+            tup = tuple(t.detach() for t in hit) if hit is not None else conv_plan.cached_on(w0, ("styles", 0), style, self._make)
+        for c, s in zip(self.convs, tup):
+            c.__dict__["_pre_style"] = (style, s)
+        self.set = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.set:
+            for c in self.convs:
+                c.__dict__.pop("_pre_style", None)
 
 
 class StyledConv_without_noise(nn.Module):

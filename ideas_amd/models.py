@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .model import (CL, Blur, EqualConv2d, EqualLinear, ScaledLeakyReLU,
-                    StyledConv_without_noise as StyledConv)
+                    StyledConv_without_noise as StyledConv, styles_for)
 from .op import FusedLeakyReLU, conv2d, conv_transpose2d, upfirdn2d
 from .op.conv import down_pair, down_pair_ok, fork_conv2d
 from .op.upfirdn2d import fork_down2, upfirdn2d_up2_add
@@ -335,8 +335,10 @@ class Generator(nn.Module):
 
     def forward(self, structure, texture, noises=None):
         out = structure
-        for layer in self.layers:
-            out = layer(out, texture, None)
+        # all sixteen modulation layers read `texture`: their styles come from one batched launch (model.styles_for)
+        with styles_for([c.conv for layer in self.layers for c in (layer.conv1, layer.conv2)], texture):
+            for layer in self.layers:
+                out = layer(out, texture, None)
         return to_f32(self.to_rgb(out))
 
 

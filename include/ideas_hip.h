@@ -384,6 +384,44 @@ int ideas_patch_resize(void* y, const void* x, const int* boxes, int n_crop, int
 int ideas_patch_resize_bwd(float* gx, const void* gy, const int* boxes, int n_crop, int B, int C, int H, int W, int out_h,
                            int out_w, int clear, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * EqualLinear (stylegan2/model.py:131-160:  F.linear(input, weight * scale, bias * lr_mul)) for MANY layers sharing one input, one
+ * launch per direction.  Replaces the ATen / vendor-GEMM calls behind F.linear on this path: every linear layer of IDEAS is skinny
+ * (M = batch <= a few hundred rows, K = 32 .. 8192, N = 1 .. 512), and the generator applies sixteen of them (the modulation layers
+ * of its StyledConvs, stylegan2/model.py:226,239) to the same texture code.  (additive since ABI version 3.)
+ *
+ * A segment = one layer.  All matrices are f32 row-major with explicit row strides (in floats, multiples of 4; 16-byte aligned bases):
+ *     w    [n][K]   the layer's weight (ldw)               bias [n] or NULL
+ *     y    [M][n]   forward: the output;  backward: the incoming gradient g = dL/dy (ldy)
+ *     gw   [n][K]   ideas_linear_bwd_w: the weight gradient (ldgw);   gb [n] or NULL: the bias gradient
+ *     scale         the equalised-lr factor (1/sqrt(K) * lr_mul);   bias_mul = lr_mul
+ * tile0 / pad_ are scratch of the library (any value).
+ *   ideas_linear_fwd     y_s[m][j]   = scale_s * sum_k x[m][k] w_s[j][k] + bias_mul_s * bias_s[j]             (K % 8 == 0)
+ *   ideas_linear_bwd_x   gx[m][k]    = sum_s scale_s * sum_j y_s[m][j] w_s[j][k]       (ONE tensor: the sum over the segments, i.e. what
+ *                                      autograd would add up for an input used by every layer; n_s % 8 == 0, K % 4 == 0).
+ *                                      `workspace`: >= ideas_linear_bwd_x_workspace(sum n_s, M, K) bytes of device scratch
+ *                                      (split partial sums, folded in a fixed order: no atomics, reproducible).
+ *   ideas_linear_bwd_w   gw_s[j][k] (+)= scale_s * sum_m y_s[m][j] x[m][k];   gb_s[j] (+)= bias_mul_s * sum_m y_s[m][j]
+ *                                      (`accumulate` != 0: add to what gw / gb hold -- e.g. the optimiser's gradient buffer; K % 4 == 0)
+ * Arithmetic: v_mfma_f32_32x32x2_f32 (exact f32 fused multiply-adds), fixed summation order. */
+#define IDEAS_LINEAR_MAX_SEGMENTS 32
+typedef struct ideas_linear_seg {
+    const float* w;
+    const float* bias;
+    float* y;
+    float* gw;
+    float* gb;
+    int n, ldw, ldy, ldgw;
+    float scale, bias_mul;
+    int tile0, pad_;
+} ideas_linear_seg;
+int ideas_sizeof_linear_seg(void);
+int ideas_linear_fwd(const ideas_linear_seg* segs, int nseg, const void* x, int M, int K, int ldx, void* stream);
+int64_t ideas_linear_bwd_x_workspace(int total_n, int M, int K);
+int ideas_linear_bwd_x(const ideas_linear_seg* segs, int nseg, void* gx, int M, int K, int ldgx, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+int ideas_linear_bwd_w(const ideas_linear_seg* segs, int nseg, const void* x, int M, int K, int ldx, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

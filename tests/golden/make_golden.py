@@ -588,10 +588,13 @@ def gen_step(RM, RU, RL, RO, which):
     d_reg_every = 2
     width = dict(channel=4, texture_channel=64, cm_den=8)
     if which == "r256_full":
-        # The bench's architecture (train.py:344-356 defaults: channel 32, texture_channel 2048, multiplier 1) inside ONE iteration
-        # of the unmodified train(), R1 included (d_reg_every = 1): 512-channel layers and the 2048-d texture code inside a
-        # reference-anchored step.  ~2 minutes of CPU; the weights regenerate from the seed, so only draws / losses / norms are stored.
-        n_iters, d_reg_every = 1, 1
+        # The bench's architecture (train.py:344-356 defaults: channel 32, texture_channel 2048, multiplier 1) inside TWO iterations
+        # of the unmodified train(): 512-channel layers and the 2048-d texture code inside a reference-anchored step, the second
+        # iteration (round 5) with the R1 branch (d_reg_every = 2) for the teacher-forced comparison at full width.  (R1 in BOTH
+        # iterations is not something the reference can run on one batch object: train.py:106 leaves X.requires_grad set, and the
+        # next iteration's `real_patch.requires_grad = True`, train.py:110, then hits a non-leaf.)  ~3 minutes of CPU; the weights
+        # regenerate from the seed, so only draws / losses / norms are stored.
+        n_iters, d_reg_every = 2, 2
         width = dict(channel=32, texture_channel=2048, cm_den=1)
         args = ns(channel=32, structure_channel=8, texture_channel=2048, N=N, image_size=R, channel_multiplier=1,
                   blur_kernel=(1, 3, 3, 1))

@@ -265,7 +265,7 @@ def test_step_replay_gpu(which):
     print(which, "gradient-direction error per optimiser step:", [(i, t, "%.1e" % e) for i, t, _, e in check_replay.last_report])
 
 
-@pytest.mark.parametrize("which", ["r64", "r256"])
+@pytest.mark.parametrize("which", ["r64", "r256", "r256_full"])
 def test_later_iterations_teacher_forced_against_oracle(which):
     """after the first optimiser step the replays above only hold DIR_BOUNDS[2] = 0.25, because Adam's first
     update is lr * sign(g) and parameters at the noise floor then differ by +-lr between ANY two evaluations (the reference
@@ -277,9 +277,12 @@ def test_later_iterations_teacher_forced_against_oracle(which):
     parameter gradient (all parameters above the group's noise floor, full tensors, not sketches) to |dg|/|g| < 6e-3 in the D
     step -- the only one taken on exactly the oracle's weights; measured 1.3e-4 (r64) / 5.6e-5 (r256) -- and < 2e-2 in the R1, G and
     Ex steps, which follow the trainer's own D (and R1) updates of that iteration (measured 1.3e-3 / 7.0e-3): an order of magnitude
-    inside the 0.25 the un-forced replays can promise there."""
+    inside the 0.25 the un-forced replays can promise there.
+    ``r256_full`` (round 5): the same at FULL width -- channel 32, texture 2048, 512-channel layers -- on the
+    second iteration of the reference's train() fixture, which there carries the lazy-R1 branch (real Dco included)."""
+    import os
     from test_host_logic import _oracle_trainer
-    torch.set_num_threads(8)
+    torch.set_num_threads(max(8, min(32, os.cpu_count() or 8)))
     snaps, ga, gb = {}, [], []
 
     def snap(it, tr):

@@ -1269,6 +1269,127 @@ def test_grad_sink_modulated_conv_and_linear(ops):
         assert rel_err(p.grad, 2 * g) < 3e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))
 
 
+# --------------------------------------------------------------------------------------------- EqualLinear on csrc/linear.hip
+@pytest.mark.parametrize("hip", [True, False])
+def test_equal_linear_golden(ops_golden, hip, monkeypatch):
+    """EqualLinear (stylegan2/model.py:131-160) on the reference's own vectors -- plain, with the fused activation, and the
+    modulation layer's bias_init = 1 -- forward, input / weight / bias gradients (an op-level GPU test of
+    equal_linear; the 10 -> 7 layer has K % 8 != 0, so the HIP kernels are exercised on a zero-padded copy of the same numbers as
+    well as the library-GEMM form the module takes for that shape)."""
+    from ideas_amd.model import EqualLinear
+    from ideas_amd.op import linear as L
+    g = ops_golden
+    monkeypatch.setattr(L, "LINEAR_HIP", hip)
+    for tag, act in (("lin", None), ("linact", "fused_lrelu"), ("linmod", None)):
+        x, w, b = (g.t(f"{tag}.{k}") for k in "xwb")
+        pad = 16 - x.shape[1] if hip else 0                  # K = 10 -> 16 with zero columns: the same products, HIP kernels
+        xd = dev(F.pad(x, (0, pad))).requires_grad_(True)
+        m = EqualLinear(x.shape[1] + pad, w.shape[0], activation=act).cuda()
+        m.scale = 1 / math.sqrt(x.shape[1])                  # the reference layer's equalised-lr scale (K = 10)
+        with torch.no_grad():
+            m.weight.copy_(F.pad(w, (0, pad)))
+            m.bias.copy_(b)
+        y = m(xd)
+        assert rel_err(y, g.t(f"{tag}.y")) < TOL, (tag, hip)
+        gx, gw, gb = torch.autograd.grad(y, (xd, m.weight, m.bias), dev(g.t(f"{tag}.gy")))
+        n = x.shape[1]
+        assert rel_err(gx[:, :n], g.t(f"{tag}.gx")) < GTOL and rel_err(gw[:, :n], g.t(f"{tag}.gw")) < GTOL, (tag, hip)
+        assert rel_err(gb, g.t(f"{tag}.gb")) < GTOL, (tag, hip)
+        if pad:
+            assert float(gw[:, n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(32, 2048, (8, 128, 128, 256, 512)), (96, 8192, (512,)), (7, 64, (40, 8)), (256, 1536, (1024,)),
+                                  (33, 520, (24, 100))])
+def test_linear_kernels_vs_float64(case):
+    """ideas_linear_fwd / _bwd_x / _bwd_w (csrc/linear.hip) on random data against f64: several layers sharing one input (the
+    generator's modulation layers, M = 32, K = 2048), the discriminator head (M = 96, K = 8192), ragged M / N / K (M not a multiple
+    of 32, N of 32, K of 512), with and without bias; the input gradient is the SUM over the layers."""
+    from ideas_amd.op.linear import multi_linear
+    M, K, ns = case
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K, dtype=torch.float64).requires_grad_(True)
+    ws = [torch.randn(n, K, dtype=torch.float64).requires_grad_(True) for n in ns]
+    bs = [None if i == 1 else torch.randn(n, dtype=torch.float64).requires_grad_(True) for i, n in enumerate(ns)]
+    scales = [1 / math.sqrt(K) * (1 + 0.5 * i) for i in range(len(ns))]
+    bmuls = [1.0 if i % 2 == 0 else 0.25 for i in range(len(ns))]
+    ys = [s * (x @ w.t()) + (0 if b is None else bm * b) for w, b, s, bm in zip(ws, bs, scales, bmuls)]
+    gys = [torch.randn_like(y) for y in ys]
+    leaves = [x] + ws + [b for b in bs if b is not None]
+    ref = torch.autograd.grad(ys, leaves, gys)
+    t = lambda v: None if v is None else v.detach().float().cuda().requires_grad_(True)
+    xd, wd, bd = t(x), [t(w) for w in ws], [t(b) for b in bs]
+    yd = multi_linear(xd, [(w, b, s, bm) for w, b, s, bm in zip(wd, bd, scales, bmuls)])
+    assert type(yd[0].grad_fn).__name__.startswith("_MultiLinear"), "the HIP kernels did not run"
+    for a, r in zip(yd, ys):
+        assert rel_err(a, r) < TOL
+    got = torch.autograd.grad(yd, [xd] + wd + [b for b in bd if b is not None], [g.float().cuda() for g in gys])
+    for a, r in zip(got, ref):
+        assert rel_err(a, r) < (GTOL if all(n % 8 == 0 for n in ns) else 3 * GTOL), (case, tuple(r.shape), rel_err(a, r))
+    # reproducible: no atomics anywhere (fixed split order)
+    got2 = torch.autograd.grad(multi_linear(xd, [(w, b, s, bm) for w, b, s, bm in zip(wd, bd, scales, bmuls)]),
+                               [xd] + wd + [b for b in bd if b is not None], [g.float().cuda() for g in gys])
+    assert all(torch.equal(a, b) for a, b in zip(got, got2))
+
+
+def test_linear_double_backward_and_sink():
+    """The HIP linear Function under create_graph (R1 through the discriminator heads, train.py:105-129): its backward re-expresses
+    itself with differentiable ops, second derivatives equal the f64 composite; inside grad_sink the weight / bias gradients of a
+    multi-layer call accumulate in place (twice the plain gradients after two passes)."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.linear import equal_linear, multi_linear
+    torch.manual_seed(11)
+    x = torch.randn(5, 64, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(16, 64, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(16, dtype=torch.float64).requires_grad_(True)
+    f = lambda x_, w_, b_, lin: (lin(x_, w_, b_) ** 3).sum()
+    ref_lin = lambda x_, w_, b_: 0.125 * (x_ @ w_.t()) + b_
+    (gx,) = torch.autograd.grad(f(x, w, b, ref_lin), x, create_graph=True)
+    ref = torch.autograd.grad((gx ** 2).sum(), (x, w, b))
+    xd, wd, bd = (v.detach().float().cuda().requires_grad_(True) for v in (x, w, b))
+    (gxd,) = torch.autograd.grad(f(xd, wd, bd, lambda x_, w_, b_: equal_linear(x_, w_, b_, 0.125)), xd, create_graph=True)
+    assert rel_err(gxd, gx) < GTOL
+    got = torch.autograd.grad((gxd ** 2).sum(), (xd, wd, bd))
+    for a, r in zip(got, ref):
+        assert rel_err(a, r) < 3 * GTOL
+    # gradient sink
+    ws = [torch.nn.Parameter(torch.randn(n, 64, device="cuda")) for n in (8, 40)]
+    bs = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (8, 40)]
+    xs = torch.randn(6, 64, device="cuda", requires_grad=True)
+    loss = lambda: sum((y ** 2).mean() for y in multi_linear(xs, [(w_, b_, 0.1, 1.0) for w_, b_ in zip(ws, bs)]))
+    params = ws + bs
+    ref = torch.autograd.grad(loss(), params)
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    for _ in range(2):
+        with CV.grad_sink(params):
+            loss().backward()
+    for p, g_ in zip(params, ref):
+        assert rel_err(p.grad, 2 * g_) < 3e-5
+
+
+def test_generator_batched_styles_equal_the_per_layer_path(monkeypatch):
+    """models.Generator with the sixteen modulation layers as one multi_linear node (model.styles_for) against the per-layer path:
+    same image (bitwise: the same kernels produce each style... up to the GEMM, so 1e-6), same gradients for the texture code, the
+    modulation weights and biases."""
+    from ideas_amd import model as MD, train_step as TS
+    from ideas_amd.models import init_model
+    args = TS.default_args(channel=8, texture_channel=128, image_size=64)
+    torch.manual_seed(2)
+    G = init_model("Generator", args).cuda()
+    S = torch.randn(2, 8, 4, 4, device="cuda")
+    T = torch.randn(2, 128, device="cuda", requires_grad=True)
+    params = [p for n, p in G.named_parameters() if "modulation" in n]
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(MD, "BATCH_STYLES", flag)
+        img = G(S, T)
+        res.append((img, torch.autograd.grad((img ** 2).mean(), [T] + params)))
+    assert rel_err(res[0][0], res[1][0]) < 2e-6
+    for a, b in zip(res[0][1], res[1][1]):
+        assert rel_err(a, b) < 2e-5, (tuple(a.shape), rel_err(a, b))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # patchify_image's crop + bilinear resize (utils.py:127-149) on ideas_patch_resize (csrc/patchify.hip)
 # ---------------------------------------------------------------------------------------------------------------
