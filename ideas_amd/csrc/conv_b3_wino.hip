@@ -159,6 +159,57 @@ __device__ __forceinline__ bool wino_vec_ok(const float* y, const float* resid, 
     return (Cout & 3) == 0 && (((uintptr_t)y | (uintptr_t)resid | (uintptr_t)out_scale | (uintptr_t)bias) & 15) == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Branch-free tails for the epilogue configurations the training step actually launches (round 5).  wino_finish4 tests five run-time
+// flags per channel quad (out_scale / bias / act / resid / accumulate): uniform branches, but each one ends a basic block, so its
+// loads are waited for one by one and nothing is packed -- ~600 of a wave's ~1550 vector instructions per 8-chunk tile, executed
+// with the matrix pipe idle.  Here the configuration is a template parameter chosen by ONE uniform switch per
+// half tile, a thread finishes its 8 channels x 2 pixels in straight-line code on 4-wide vectors (v_pk_add / v_pk_mul; no
+// contraction: the op order and roundings are wino_finish4's, the results bitwise equal), the leaky-ReLU is max(t, alpha t)
+// (equal to the select for 0 <= alpha <= 1, the only slopes admitted), and the four stores take 32-bit buffer offsets.
+//   OS: per-(sample, channel) output scale   BA: bias + leaky-ReLU * act_gain   RS: (v + resid) * resid_gain
+// ---------------------------------------------------------------------------------------------------------------
+enum { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_OS = 2, EPI_BA = 3, EPI_OS_BA = 4, EPI_OS_BA_RS = 5 };
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool OS, bool BA, bool RS>
+__device__ __forceinline__ void wino_finish_fast(__amdgpu_buffer_rsrc_t ry, unsigned yoff, unsigned px_step, const float* __restrict__ resid,
+                                                 const float* __restrict__ os_p, const float* __restrict__ bias_p,
+                                                 const float* __restrict__ ex, bool two, float gain, float alpha, float act_gain,
+                                                 float resid_gain) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (g == 1 && !two) break;
+        const v4f m0 = *reinterpret_cast<const v4f*>(ex + g * 4 + 0 * WP * XROW);
+        const v4f m1 = *reinterpret_cast<const v4f*>(ex + g * 4 + 1 * WP * XROW);
+        const v4f m2 = *reinterpret_cast<const v4f*>(ex + g * 4 + 2 * WP * XROW);
+        const v4f m3 = *reinterpret_cast<const v4f*>(ex + g * 4 + 3 * WP * XROW);
+        v4f osv, bv, r0, r1;
+        if (OS) osv = *reinterpret_cast<const v4f*>(os_p + g * 4);
+        if (BA) bv = *reinterpret_cast<const v4f*>(bias_p + g * 4);
+        if (RS) {
+            r0 = *reinterpret_cast<const v4f*>(resid + (yoff >> 2) + g * 4);
+            r1 = *reinterpret_cast<const v4f*>(resid + ((yoff + px_step) >> 2) + g * 4);
+        }
+        v4f t0 = (m0 + m1) + m2, t1 = (m1 - m2) - m3;
+        t0 = t0 * gain; t1 = t1 * gain;
+        if (OS) { t0 = t0 * osv; t1 = t1 * osv; }
+        if (BA) {
+            t0 = t0 + bv; t1 = t1 + bv;
+            const v4f a0 = t0 * alpha, a1 = t1 * alpha;
+            t0 = __builtin_elementwise_max(t0, a0) * act_gain;
+            t1 = __builtin_elementwise_max(t1, a1) * act_gain;
+        }
+        if (RS) { t0 = (t0 + r0) * resid_gain; t1 = (t1 + r1) * resid_gain; }
+        // (no SGPR offset on the stores: conv_b3_s2fir.hip records the data hazard of the `soffset` form on this part)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, t0), ry,
+                                               (int)(yoff + g * 16), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, t1), ry,
+                                               (int)(yoff + px_step + g * 16), 0, 0);
+    }
+}
+
 template <bool SCALE, bool REFLECT, int NH>
 __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                               const void* __restrict__ uplanes,
@@ -166,7 +217,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
                                                               const float* __restrict__ out_scale,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ resid, ideas_conv_params p,
-                                                              int tiles_n, unsigned x_bytes, unsigned plane_bytes) {
+                                                              int tiles_n, unsigned x_bytes, unsigned plane_bytes, int epi) {
     constexpr int KS = BK * NH;                 // channels per K-step
     constexpr int KQ = 4 * NH;                  // float4 quads per row and step
     constexpr int RB = ROWB * NH;               // bytes per LDS row
@@ -398,6 +449,8 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
     // ---- epilogue: the four components meet in LDS, inverse transform, fused gain / demod / bias / act / residual -----
     float* exch = reinterpret_cast<float*>(smem);       // [NH halves][4 v][64 rows][XROW]
     const bool vec = wino_vec_ok(y, resid, out_scale, bias, p.Cout);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)y, 0, epi != EPI_GENERIC ? (int)((unsigned)p.B * (unsigned)p.IH * (unsigned)p.IW * (unsigned)p.Cout * 4u) : 0, (int)RSRC_FLAGS);
     const int er = (t >> 2) & 63, cg = t & 3, eh = t >> 8;   // this thread finishes 8 channels of pair row er, half eh
     const bool row_live = m0 + er < M;
     int pb = 0;
@@ -417,7 +470,23 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 3 : 1) void conv_b3_wino_kernel
             for (int e = 0; e < 16; ++e)
                 exch[((wh * 4 + wv) * WP + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * XROW + li] = acc[a][hb][e];
         __syncthreads();
-        if (row_live) {
+        if (row_live && epi != EPI_GENERIC) {            // (uniform switch; see wino_finish_fast)
+            const int n = n0 + eh * 64 + hb * 32 + cg * 8;
+            if (n < p.Cout) {
+                const float* ex = exch + (eh * 4 * WP + er) * XROW + cg * 8;
+                const unsigned yoff = (unsigned)(opix + n) * 4u, pxs = (unsigned)p.Cout * 4u;
+                const float* osp = out_scale + (int64_t)pb * p.Cout + n;
+                const float* bp = bias + n;
+                const bool two = n + 4 < p.Cout;
+                switch (epi) {
+                    case EPI_PLAIN: wino_finish_fast<false, false, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    case EPI_OS: wino_finish_fast<true, false, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    case EPI_BA: wino_finish_fast<false, true, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    case EPI_OS_BA: wino_finish_fast<true, true, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    default: wino_finish_fast<true, true, true>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                }
+            }
+        } else if (row_live) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int cl = cg * 8 + g * 4;           // channel offset inside the 32-channel slice
@@ -463,7 +532,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
                                                                 const float* __restrict__ out_scale,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ resid, ideas_conv_params p,
-                                                                int tiles_n, unsigned x_bytes, unsigned plane_bytes, int ntiles) {
+                                                                int tiles_n, unsigned x_bytes, unsigned plane_bytes, int ntiles, int epi) {
     constexpr int TR = WP / TP;                 // output rows of the patch
     constexpr int SR = (TR + 2) * TP;           // staged pair-rows per chunk
     constexpr int PL = SR * ROWB;               // bytes per plane
@@ -484,6 +553,9 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)uplanes, 0, (int)(12u * plane_bytes), (int)RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)in_scale, 0, SCALE ? p.B * p.Cin * 4 : 0, (int)RSRC_FLAGS);
+    // (the fast epilogues store through a buffer resource with 32-bit offsets; num_records = 0 when they are not in use)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)y, 0, epi != EPI_GENERIC ? (int)((unsigned)p.B * (unsigned)H * (unsigned)W * (unsigned)p.Cout * 4u) : 0, (int)RSRC_FLAGS);
 
     // ---- staging: thread = (staged pair-row r, channel quad kq of the chunk); threads past SR * 4 idle in the staging parts ----
     const int r = t >> 2, kq = t & 3;
@@ -708,6 +780,24 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
             for (int e = 0; e < 16; ++e)
                 exch[((wh * 4 + wv) * WP + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * XROW + li] = acc[a][hb][e];
         __syncthreads();
+        if (epi != EPI_GENERIC) {
+            // (the launcher checked: 16-byte addressable rows, Cout % 4 == 0, y below 4 GB, 0 <= alpha <= 1, no accumulate)
+            const int n = e_n0 + eh * 64 + hb * 32 + cg * 8;
+            if (n < p.Cout) {
+                const float* ex = exch + (eh * 4 * WP + er) * XROW + cg * 8;
+                const unsigned yoff = (unsigned)(opix + n) * 4u, pxs = (unsigned)p.Cout * 4u;
+                const float* osp = out_scale + (int64_t)e_pb * p.Cout + n;
+                const float* bp = bias + n;
+                const bool two = n + 4 < p.Cout;
+                switch (epi) {                           // uniform
+                    case EPI_PLAIN: wino_finish_fast<false, false, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    case EPI_OS: wino_finish_fast<true, false, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    case EPI_BA: wino_finish_fast<false, true, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    case EPI_OS_BA: wino_finish_fast<true, true, false>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                    default: wino_finish_fast<true, true, true>(ry, yoff, pxs, resid, osp, bp, ex, two, p.gain, p.alpha, p.act_gain, p.resid_gain); break;
+                }
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int cl = cg * 8 + g * 4;
@@ -722,6 +812,7 @@ __global__ __launch_bounds__(512, 1) void conv_b3_wino2d_kernel(float* __restric
                                         {m2v.x, m2v.y, m2v.z, m2v.w}, {m3v.x, m3v.y, m3v.z, m3v.w}};
                 wino_finish4(y, resid, out_scale, bias, p, mm, opix, e_pb, n, vec);
             }
+        }
         }
         __syncthreads();
     }
@@ -770,13 +861,25 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
     const bool use2d = !(e2d && e2d[0] == '0');
     const int W2 = p->IW / 2;
     const int TPsel = (W2 % 32 == 0) ? 32 : (W2 % 16 == 0) ? 16 : (W2 % 8 == 0) ? 8 : 0;
+    // epilogue configuration (wino_finish_fast): IDEAS_B3_WINO_EPI=0 keeps the flag-testing tail everywhere (A/B measurements)
+    int epi = EPI_GENERIC;
+    {
+        const char* eepi = getenv("IDEAS_B3_WINO_EPI");
+        const bool vec = p->Cout % 4 == 0 && ((((uintptr_t)y | (uintptr_t)resid | (uintptr_t)out_scale | (uintptr_t)bias) & 15) == 0);
+        if (!(eepi && eepi[0] == '0') && vec && !p->accumulate && (int64_t)p->B * p->IH * p->IW * p->Cout * 4 < 0xffffffffLL) {
+            const bool ba = bias && p->act && p->alpha >= 0.f && p->alpha <= 1.f;
+            if (!bias && !p->act && !resid) epi = out_scale ? EPI_OS : EPI_PLAIN;
+            else if (ba && !resid) epi = out_scale ? EPI_OS_BA : EPI_BA;
+            else if (ba && resid && out_scale) epi = EPI_OS_BA_RS;
+        }
+    }
     if (wide && use2d && TPsel && p->IH % (WP / TPsel) == 0 && p->Cin % 16 == 0) {
         auto go2 = [&](auto sc, auto rf, auto tp) {
             const int64_t nt = tm * tn;                       // persistent: one block per CU (98 KB of LDS each), a multiple of 8
             const unsigned grid = (unsigned)(nt < 256 ? nt : 256);
             hipLaunchKernelGGL((conv_b3_wino2d_kernel<decltype(sc)::value, decltype(rf)::value, decltype(tp)::value>),
                                dim3(grid), dim3(512), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale,
-                               bias, (const float*)resid, *p, tn, x_bytes, plane_bytes, (int)nt);
+                               bias, (const float*)resid, *p, tn, x_bytes, plane_bytes, (int)nt, epi);
         };
         using T = std::true_type;
         using F = std::false_type;
@@ -793,11 +896,11 @@ int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* 
         if (wide)
             hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value, 2>), dim3((unsigned)(tm * tn)),
                                dim3(512), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale, bias,
-                               (const float*)resid, *p, tn, x_bytes, plane_bytes);
+                               (const float*)resid, *p, tn, x_bytes, plane_bytes, epi);
         else
             hipLaunchKernelGGL((conv_b3_wino_kernel<decltype(sc)::value, decltype(rf)::value, 1>), dim3((unsigned)(tm * tn)),
                                dim3(256), 0, stream, (float*)y, (const float*)x, uplanes, in_scale, out_scale, bias,
-                               (const float*)resid, *p, tn, x_bytes, plane_bytes);
+                               (const float*)resid, *p, tn, x_bytes, plane_bytes, epi);
     };
     using T = std::true_type;
     using F = std::false_type;

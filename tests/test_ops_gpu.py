@@ -482,6 +482,45 @@ def test_winograd_kernels_vs_direct_and_oracle(case):
     assert rel_err(res[True][0], res[False][0]) < 5e-6
 
 
+@pytest.mark.parametrize("case", [(2, 32, 128, 16, 64, False), (1, 64, 200, 8, 32, False), (2, 128, 128, 32, 16, True), (1, 32, 68, 8, 64, False),
+                                  (2, 32, 64, 16, 32, False), (3, 16, 36, 9, 14, True), (2, 64, 128, 6, 12, False)])   # last three: the 4-wave tile (Cout <= 64, ragged rows) and the 8-wave tile without row sharing
+@pytest.mark.parametrize("epi", ["plain", "os", "ba", "os_ba", "os_ba_rs"])
+def test_winograd_fast_epilogues_are_bitwise_the_generic_tail(case, epi, monkeypatch):
+    """The row-sharing Winograd kernel finishes a tile through one of five branch-free specialisations of its epilogue
+    (csrc/conv_b3_wino.hip::wino_finish_fast: packed f32 arithmetic, max(t, alpha t), buffer stores) chosen from the launch's flags;
+    IDEAS_B3_WINO_EPI=0 keeps the flag-testing tail (wino_finish4).  Same op order and roundings: the outputs must be BITWISE equal,
+    for every configuration the step launches (plain input gradient; modulated input gradient = output scale; conv + bias +
+    leaky-ReLU; modulated conv + bias + act; the same with the residual merge), ragged last channel blocks (Cout = 200, 68) and
+    mirror padding included; and within tolerance of f64."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, refl = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    w = torch.randn(co, ci, 3, 3, dtype=torch.float64)
+    os_ = (torch.rand(B, co, dtype=torch.float64) + 0.5) if "os" in epi else None
+    ins = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if "os" in epi else None
+    bias = torch.randn(co, dtype=torch.float64) * 0.3 if "ba" in epi else None
+    resid = torch.randn(B, co, H, W, dtype=torch.float64) if "rs" in epi else None
+    xs = x * ins.view(B, ci, 1, 1) if ins is not None else x
+    y = F.conv2d(F.pad(xs, [1] * 4, mode="reflect") if refl else xs, w * 0.07, padding=0 if refl else 1)
+    if os_ is not None:
+        y = y * os_.view(B, co, 1, 1)
+    if bias is not None:
+        y = F.leaky_relu(y + bias.view(1, -1, 1, 1), 0.2) * 1.3
+    if resid is not None:
+        y = (y + resid) * 0.5
+    g = ConvGeom(3, 3, 1, 1, refl)
+    t = lambda v, cl=False: None if v is None else dev(v.float(), cl)
+    args = dict(lin=t(ins), lout=t(os_), bias=t(bias), act=bias is not None, act_gain=1.3, alpha=0.2, resid=t(resid, True), resid_gain=0.5)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_B3_WINO_EPI", flag)
+        outs.append(CV.conv_fwd_raw(dev(x.float(), True), dev(w.float(), True), g, 0.07, **args))
+    assert rel_err(outs[0], y) < TOL
+    assert torch.equal(outs[0], outs[1]), (case, epi, float((outs[0] - outs[1]).abs().max()))
+
+
 def test_winograd_full_size_properties():
     """BASELINE-size check (G.layers.7.conv2: 128->128 @256x256, B=8) through size-independent properties:
     linearity in the input, agreement with the direct kernel, and <gy, conv(x)> == <dgrad(gy), x> (adjointness)."""
