@@ -113,6 +113,10 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
                  const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);
 int ideas_b3_fwd_multi(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
                        const ideas_conv_params* ps, hipStream_t stream);
+// conv_b3_pw.hip: 1x1 / stride-1 layers with Cin <= 128 as a flat HBM-bound GEMM (ideas_b3_pw_ok decides; same results as ideas_b3_fwd)
+int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale);
+int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bias, const void* resid, const ideas_conv_params* p,
+                    hipStream_t stream);
 // conv_b3_tphase.hip: the four phases of a 3x3 / stride-2 / pad-0 transposed conv in one pass over a shared LDS image of the input
 // (-1: the launches are not that geometry -> conv_b3_multi_kernel)
 int ideas_b3_fwd_tphase(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,

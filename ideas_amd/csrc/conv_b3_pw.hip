@@ -1,0 +1,201 @@
+// Pointwise (1x1, stride 1) convolutions with few input channels as a flat, HBM-bound GEMM  y[M][Cout] = gain * x[M][Cin] . W^T
+// on the split-bf16 contraction of b3.hpp -- the skip branches of the residual blocks (models.py:195-206, 170-178: a 1x1 conv behind
+// the decimating FIR / in front of the zero-stuffing one), their input gradients, and the other 1x1 layers with Cin <= 128.
+//
+// Why a kernel of its own (round 5): the per-launch census of the step (tools/step_census2.py) shows the 1x1 layers on the generic
+// conv_b3_kernel at 16-51 TFLOP/s where they are bound by HBM, not by the matrix pipe -- [96 x 128 x 128] pixels, 64 -> 128 channels
+// moves 1.2 GB and took 0.90 ms (1.3 TB/s).  With K = Cin = 64 a 128 x 128 tile is four K-steps between a prologue that derives every
+// row's address with divisions, two block barriers and an epilogue that looks every row up in LDS: the tile's fixed costs are the
+// kernel.  A flat GEMM needs none of it:
+//   * the x tile of BM pixels is ONE contiguous run of BM * Cin floats (NHWC, no padding, no stride): thread t fetches 16-byte
+//     pieces t, t + 256, ...: perfectly coalesced, and the same addresses plus a tile stride for every tile;
+//   * all of K fits in LDS at once (three bf16 planes of BM x Cin = 48 KB), so a tile is: split + store, ONE barrier, contract,
+//     store -- and the next tile's loads are already in flight (register prefetch) while this one is contracted;
+//   * a wave owns 32 output channels and keeps its weight fragments for ALL of K in registers (Cin / 16 x 3 planes x 4 VGPRs) for
+//     the whole launch when Cout <= 128: the K loop issues no weight load at all (more output channels: passes of 128, fragments
+//     re-read from L2 per pass);
+//   * blocks are persistent (two per CU) and walk tiles b, b + G, ...; rows past M and channels past Cout cost nothing: the loads
+//     return zeros (buffer bounds), the stores are dropped by the same bounds / an out-of-range offset.
+// Arithmetic, op order and epilogue (gain, bias, leaky-ReLU, residual) are those of conv_b3_kernel: each output is the same six
+// plane-pair MFMA chains over K in the same order, so results are BITWISE the generic kernel's (tests/test_ops_gpu.py).
+#include "b3.hpp"
+#include <cstdlib>
+
+namespace {
+
+// NWC = waves side by side along the channels (4: passes of 128 channels, every wave all MT row blocks; 2: passes of 64 channels, the
+// upper two waves take the lower half of the rows -- Cout <= 64 would leave two of four waves without work otherwise)
+template <int KS, int MT, int NWC>
+__global__ __launch_bounds__(256, 2) void conv_b3_pw_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                            const void* __restrict__ wplanes, const float* __restrict__ bias,
+                                                            const float* __restrict__ resid, ideas_conv_params p, unsigned M,
+                                                            unsigned plane_bytes, int ntiles, int npass) {
+    constexpr int CIN = KS * 16, BM = MT * 32;
+    constexpr int Q = CIN / 4;                       // 16-byte pieces per row
+    constexpr int NV = BM * Q / 256;                 // pieces per thread and tile
+    static_assert(BM * Q % 256 == 0, "tile = whole pieces per thread");
+    constexpr int MTW = MT * NWC / 4;                // row blocks per wave
+    static_assert(MTW >= 1, "a wave owns at least one 32-row block");
+    constexpr int STEPB = BM * ROWB;                 // bytes of one K-step of one plane
+    constexpr int PLANE = KS * STEPB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PLANE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wc = wave % NWC, wr = wave / NWC;      // channel block / row group of this wave
+    const unsigned x_bytes = M * (unsigned)(CIN * 4), y_bytes = M * (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wplanes, 0, (int)(3u * plane_bytes), (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)y_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)resid, 0, resid ? (int)y_bytes : 0, (int)RSRC_FLAGS);
+
+    // staging: piece f = t + 256 j of the tile -> (row, quad) -> its 8 bytes in every plane
+    int a_lds[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = t + 256 * j, row = f / Q, q = f - row * Q;
+        a_lds[j] = (q >> 2) * STEPB + row * ROWB + (((q & 3) * 8) ^ (((row >> 3) & 1) << 4));
+    }
+    float4 pre[NV];
+    auto prefetch = [&](int tile) {
+        const unsigned base = (unsigned)tile * (unsigned)(BM * CIN * 4) + (unsigned)t * 16u;       // < x_bytes + one tile: fits 32 bits (launcher)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) pre[j] = buffer_load4(rx, base + (unsigned)j * 4096u, 0);     // rows past M: zeros
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const Split4 s = split4(pre[j]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(smem + a_lds[j] + pl * PLANE) = s.p[pl];
+        }
+    };
+    // weights of pass np: this wave's 32 channels, every K-step, three planes
+    bf16x8 fb[KS][3];
+    auto loadB = [&](int np) {
+        const unsigned voff = (unsigned)((np * (32 * NWC) + wc * 32 + li) * 32 + lh * 16);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fb[s][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    rw, (int)(voff + (unsigned)pl * plane_bytes), (int)((unsigned)s * (unsigned)p.Cout * 32u), 0));
+    };
+    const int f_off = (wr * MTW * 32 + li) * ROWB + ((lh ^ ((li >> 3) & 1)) << 4);
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    prefetch(tile);
+    if (npass == 1) loadB(0);
+    for (;;) {
+        stage();
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) prefetch(next);
+        __builtin_amdgcn_sched_barrier(0);            // the loads stay up here, in flight under the contraction
+        for (int np = 0; np < npass; ++np) {
+            if (npass > 1) loadB(np);
+            f32x16 acc[MTW];
+#pragma unroll
+            for (int a = 0; a < MTW; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 fa[MTW][3];
+#pragma unroll
+                for (int a = 0; a < MTW; ++a)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[a][pl] = *reinterpret_cast<const bf16x8*>(smem + pl * PLANE + s * STEPB + a * 32 * ROWB + f_off);
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int a = 0; a < MTW; ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb[s][PB[q]], acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);    // (the fragment reads of all K-steps at once would not fit the register file)
+            }
+            // ---- epilogue: lane = channel n, acc[a][e] = row a*32 + (e&3) + 8 (e>>2) + 4 lh: 128-byte runs per row.  The lane part of
+            // an address is ONE register (ybase), the row part is uniform and rides in the instruction's scalar offset; `cout4` is made
+            // opaque per tile so that the 16 * MT row offsets are re-derived by the scalar ALU here instead of being hoisted out of the
+            // persistent loop into 64 live registers (the first version spilled 250 of them).
+            const int n = np * (32 * NWC) + wc * 32 + li;
+            unsigned cout4 = (unsigned)p.Cout * 4u;
+            asm volatile("" : "+s"(cout4));
+            if (n < p.Cout) {
+                const float bv = bias ? bias[n] : 0.f;
+                const unsigned ybase = ((unsigned)tile * (unsigned)BM + (unsigned)(wr * MTW * 32 + 4 * lh)) * cout4 + (unsigned)n * 4u;
+#pragma unroll
+                for (int a = 0; a < MTW; ++a) {
+                    float rv[16];
+                    if (resid) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                rr, (int)ybase, (int)((unsigned)(a * 32 + (e & 3) + 8 * (e >> 2)) * cout4), 0));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = mul_rn(acc[a][e], p.gain);
+                        v = mul_then_add(v, 1.0f, bv);
+                        if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                        if (resid) v = (v + rv[e]) * p.resid_gain;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)ybase,
+                                                              (int)((unsigned)(a * 32 + (e & 3) + 8 * (e >> 2)) * cout4), 0);   // rows past M: dropped
+                    }
+                }
+            }
+        }
+        if (next >= ntiles) break;
+        tile = next;
+        __syncthreads();                              // every wave is done reading the planes
+    }
+}
+
+template <int KS, int MT>
+int launch_pw(void* y, const void* x, const void* wplanes, const float* bias, const void* resid, const ideas_conv_params* p,
+              hipStream_t stream) {
+    constexpr int BM = MT * 32;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    const int64_t ntiles = ideas_cdiv(M, BM);
+    const unsigned plane_bytes = (unsigned)((int64_t)p->Cin * p->Cout * 2);
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);        // two persistent blocks per CU
+    if (p->Cout <= 64)
+        hipLaunchKernelGGL((conv_b3_pw_kernel<KS, MT, 2>), dim3(grid), dim3(256), 0, stream, (float*)y, (const float*)x, wplanes, bias,
+                           (const float*)resid, *p, (unsigned)M, plane_bytes, (int)ntiles, (int)ideas_cdiv(p->Cout, 64));
+    else
+        hipLaunchKernelGGL((conv_b3_pw_kernel<KS, MT, 4>), dim3(grid), dim3(256), 0, stream, (float*)y, (const float*)x, wplanes, bias,
+                           (const float*)resid, *p, (unsigned)M, plane_bytes, (int)ntiles, (int)ideas_cdiv(p->Cout, 128));
+    return ideas_launch_status();
+}
+
+}  // namespace
+
+// 1 when ideas_b3_pw_fwd takes the launch: a single-tap, unit-stride, unpadded geometry whose output grid IS the input grid, without
+// per-sample scales and without accumulation, 16 <= Cin <= 128 (Cin % 16 == 0), tensors below 4 GB.  IDEAS_B3_PW=0: never (A/B).
+int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale) {
+    const char* e = getenv("IDEAS_B3_PW");
+    if (e && e[0] == '0') return 0;
+    if (in_scale || out_scale || p->accumulate || p->reflect) return 0;
+    if (p->TY != 1 || p->TX != 1 || p->sy != 1 || p->sx != 1 || p->offy != 0 || p->offx != 0) return 0;
+    if (p->osy != 1 || p->osx != 1 || p->ooy != 0 || p->oox != 0) return 0;
+    if (p->OH != p->IH || p->OW != p->IW || p->YH != p->IH || p->YW != p->IW) return 0;
+    if (p->Cin % 16 || p->Cin < 16 || p->Cin > 128 || p->Cout < 16) return 0;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    // (+ one tile of slack on the x offsets: the prefetch of the last, partial tile computes offsets past M rows)
+    return (M + 128) * p->Cin * 4 < 0xffffffffLL && M * p->Cout * 4 < 0xffffffffLL && (int64_t)p->Cin * p->Cout * 6 < 0xffffffffLL;
+}
+
+int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bias, const void* resid, const ideas_conv_params* p,
+                    hipStream_t stream) {
+    switch (p->Cin / 16) {
+        case 1: return launch_pw<1, 4>(y, x, wplanes, bias, resid, p, stream);
+        case 2: return launch_pw<2, 4>(y, x, wplanes, bias, resid, p, stream);
+        case 3: return launch_pw<3, 4>(y, x, wplanes, bias, resid, p, stream);
+        case 4: return launch_pw<4, 4>(y, x, wplanes, bias, resid, p, stream);
+        case 5: return launch_pw<5, 2>(y, x, wplanes, bias, resid, p, stream);
+        case 6: return launch_pw<6, 2>(y, x, wplanes, bias, resid, p, stream);
+        case 7: return launch_pw<7, 2>(y, x, wplanes, bias, resid, p, stream);
+        default: return launch_pw<8, 2>(y, x, wplanes, bias, resid, p, stream);
+    }
+}

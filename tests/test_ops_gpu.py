@@ -1308,6 +1308,45 @@ def test_grad_sink_modulated_conv_and_linear(ops):
         assert rel_err(p.grad, 2 * g) < 3e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))
 
 
+# --------------------------------------------------------------------------------------------- 1x1 layers as a flat GEMM
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, 16, "plain"), (3, 32, 64, 9, 14, "resid"), (1, 128, 256, 24, 8, "plain"), (2, 16, 48, 7, 5, "ba"),
+                                  (1, 96, 136, 10, 13, "resid"), (5, 128, 64, 8, 8, "ba"), (2, 112, 320, 6, 6, "plain"), (1, 80, 32, 33, 3, "resid")])
+def test_pointwise_flat_gemm_kernel_is_bitwise_the_generic_kernel(case, monkeypatch):
+    """csrc/conv_b3_pw.hip (1x1 / stride-1 layers with Cin <= 128 as a persistent flat GEMM) against f64 and BITWISE against the
+    generic split-bf16 kernel it replaces (IDEAS_B3_PW=0) -- forward, and the input gradient (the same kernel on the transposed
+    weights); every K-step count and both row-block shapes, ragged last tiles (M not a multiple of 64 / 128), channel counts that
+    are not multiples of 32 / 128 (several passes over the weights), bias + leaky-ReLU and the residual epilogue."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, kind = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    w = torch.randn(co, ci, 1, 1, dtype=torch.float64)
+    bias = torch.randn(co, dtype=torch.float64) * 0.3 if kind == "ba" else None
+    resid = torch.randn(B, co, H, W, dtype=torch.float64) if kind == "resid" else None
+    y = F.conv2d(x, w * 0.11)
+    if bias is not None:
+        y = F.leaky_relu(y + bias.view(1, -1, 1, 1), 0.2) * 1.3
+    if resid is not None:
+        y = (y + resid) * 0.7
+    gy = torch.randn(B, co, H, W, dtype=torch.float64)
+    gx = F.conv_transpose2d(gy, w * 0.11)
+    g = ConvGeom(1, 1, 1, 0, False)
+    t = lambda v, cl=False: None if v is None else dev(v.float(), cl)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_B3_PW", flag)
+        yy = CV.conv_fwd_raw(dev(x.float(), True), dev(w.float(), True), g, 0.11, bias=t(bias), act=bias is not None, act_gain=1.3,
+                             alpha=0.2, resid=t(resid, True), resid_gain=0.7)
+        gg = CV.conv_dgrad_raw(dev(gy.float(), True), dev(w.float(), True), g, (H, W), 0.11) if co % 16 == 0 and co <= 128 else None
+        outs.append((yy, gg))
+    assert rel_err(outs[0][0], y) < TOL
+    assert torch.equal(outs[0][0], outs[1][0]), (case, float((outs[0][0] - outs[1][0]).abs().max()))
+    if outs[0][1] is not None:
+        assert rel_err(outs[0][1], gx) < GTOL
+        assert torch.equal(outs[0][1], outs[1][1])
+
+
 # --------------------------------------------------------------------------------------------- EqualLinear on csrc/linear.hip
 @pytest.mark.parametrize("hip", [True, False])
 def test_equal_linear_golden(ops_golden, hip, monkeypatch):
