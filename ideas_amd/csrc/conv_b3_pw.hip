@@ -169,6 +169,137 @@ int launch_pw(void* y, const void* x, const void* wplanes, const float* bias, co
     return ideas_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers:  gw[o][ci] += gain * sum_m gy[m][o] * x[m][ci]  -- a reduction over ALL pixels of two flat
+// matrices, bound by reading them once.  conv_b3_wgrad.hip ran these at 10-110 TFLOP/s (its tiles stage 128 channels x 16 pixels per
+// 96 MFMAs with a register transpose; with one tap there is nothing to amortise that over).  Here, as in conv_b3_wgrad3.hip, the
+// operands stay PIXEL-major in LDS exactly as the 16-byte loads arrive (rows of 64 channels x bf16 = 128 B, three planes, 16-byte
+// chunks XOR-swizzled by bit 1 of the row) and the MFMA operand -- 8 consecutive pixels of one channel per lane -- is gathered by the
+// LDS transpose read ds_read_b64_tr_b16.  A block owns one 64 (o) x 64 (ci) tile and one contiguous pixel range; a step is 32 pixels:
+// every thread loads, splits and stores two 16-byte pieces of each operand, every wave (a 32 x 32 quarter of the tile) issues 12
+// MFMAs; loads run two steps ahead in registers, one barrier per step (LDS double-buffered).  The tile goes to gw with f32 atomics
+// (order not fixed, as in every split-K weight gradient of the library).  Grid = tiles x ranges in XCD-banded range-major order: the
+// tiles of one range read the same pixels and meet in one L2.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int pw_chunk_off(int r, int c) { return (r * 8 + (c ^ (((r >> 1) & 1) << 2))) * 16; }
+
+__global__ __launch_bounds__(256, 2) void conv_b3_pw_wgrad_kernel(float* __restrict__ gw, const float* __restrict__ gy,
+                                                                  const float* __restrict__ x, ideas_conv_params p, unsigned M,
+                                                                  int tiles_ci, int tiles, int ranges, unsigned rows_per_range) {
+    constexpr int STEP = 32;                             // pixels per step
+    constexpr int OPB = STEP * 128;                      // bytes of one operand buffer of one plane
+    constexpr int PLANE = 2 * OPB;                       // two buffers
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * PLANE];
+    unsigned char* const sG = smem;                      // [3 planes][2 buffers][32 rows][128 B]
+    unsigned char* const sX = smem + 3 * PLANE;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int tile, range;
+    splitk_xcd_map(blockIdx.x, tiles, ranges, tile, range);
+    const int o0 = (tile / tiles_ci) * 64, c0 = (tile % tiles_ci) * 64;
+    const unsigned m0 = (unsigned)range * rows_per_range;
+    const unsigned m1 = m0 + rows_per_range < M ? m0 + rows_per_range : M;
+    if (m0 >= m1) return;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, (int)(M * (unsigned)p.Cout * 4u), (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(M * (unsigned)p.Cin * 4u), (int)RSRC_FLAGS);
+
+    // staging: thread = (pixel t >> 4 [+ 16], channel quad t & 15)
+    const int quad = t & 15, px = t >> 4;
+    const unsigned g_cb = (unsigned)(o0 + quad * 4) * 4u, x_cb = (unsigned)(c0 + quad * 4) * 4u;
+    const unsigned gstride = (unsigned)p.Cout * 4u, xstride = (unsigned)p.Cin * 4u;
+    struct Stage { float4 g[2], xv[2]; };
+    auto gload = [&](Stage& st, unsigned m) {            // pixels m + px, m + px + 16 (past the range: zeros)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned r = m + (unsigned)(px + 16 * k);
+            const unsigned bad = r < m1 ? 0u : 0xffffffffu;
+            st.g[k] = buffer_load4(rg, (r * gstride + g_cb) | bad, 0);
+            st.xv[k] = buffer_load4(rx, (r * xstride + x_cb) | bad, 0);
+        }
+    };
+    int lds_row[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) lds_row[k] = pw_chunk_off(px + 16 * k, quad >> 1) + (quad & 1) * 8;
+    auto lstore = [&](const Stage& st, int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const Split4 sg = split4(st.g[k]), sx = split4(st.xv[k]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<uint2*>(sG + pl * PLANE + buf * OPB + lds_row[k]) = sg.p[pl];
+                *reinterpret_cast<uint2*>(sX + pl * PLANE + buf * OPB + lds_row[k]) = sx.p[pl];
+            }
+        }
+    };
+
+    // MFMA side: wave = (o half, ci half) of the tile; fragments by transpose reads (conv_b3_wgrad3.hip: lane_base / frag)
+    const int wo = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int g_q = lane & 15, g_row = g_q >> 2, g_piece = g_q & 3, g_cblk = (lane >> 4) & 1;
+    auto lane_base = [&](unsigned region, int cb) {      // rows 8 lh + g_row (+ 0, 4 by the two reads; + 16 for the second half step)
+        const int r = 8 * lh + g_row;
+        return region + (unsigned)(r * 128 + (((cb * 2 + (g_piece >> 1)) ^ (((g_row >> 1) & 1) << 2)) << 4) + (g_piece & 1) * 8);
+    };
+    const unsigned ldsG = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sG;
+    const unsigned ldsX = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sX;
+    const unsigned baseG = lane_base(ldsG, wo * 2 + g_cblk), baseX = lane_base(ldsX, wc * 2 + g_cblk);
+    auto tr_ld = [&](unsigned addr) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)addr);
+    };
+    auto frag = [&](unsigned base, int off) -> bf16x8 {  // 8 pixels (rows r0 + 8 lh .. + 7; r0 a multiple of 16: the swizzle bit is g_row's)
+        const s16x4 a = tr_ld(base + (unsigned)off);
+        const s16x4 b = tr_ld(base + (unsigned)off + 512u);
+        const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {           // two 16-pixel K-steps
+            bf16x8 fa[3], fb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                fa[pl] = frag(baseG, pl * PLANE + buf * OPB + half * 16 * 128);
+                fb[pl] = frag(baseX, pl * PLANE + buf * OPB + half * 16 * 128);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]], fb[PB[q]], acc, 0, 0, 0);
+        }
+    };
+
+    // pipeline: loads of step n + 2 in flight, step n + 1 split into LDS[(n+1)&1], step n multiplied from LDS[n&1]
+    const unsigned nsteps = (m1 - m0 + STEP - 1) / STEP;
+    Stage st0, st1;
+    gload(st0, m0);
+    gload(st1, m0 + STEP);
+    lstore(st0, 0);
+    __syncthreads();
+    unsigned n = 0;
+    for (; n + 1 < nsteps; n += 2) {
+        gload(st0, m0 + (n + 2) * STEP);
+        lstore(st1, 1);
+        compute(0);
+        __syncthreads();
+        gload(st1, m0 + (n + 3) * STEP);
+        lstore(st0, 0);
+        compute(1);
+        __syncthreads();
+    }
+    if (n < nsteps) compute(0);
+
+    // D rows = o: (e & 3) + 8 (e >> 2) + 4 lh, column = ci: li; gw is [Cout][Cin] (OHWI with one tap)
+    const int ci = c0 + wc * 32 + li;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int o = o0 + wo * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        atomicAdd(&gw[(int64_t)o * p.Cin + ci], acc[e] * p.gain);
+    }
+}
+
 }  // namespace
 
 // 1 when ideas_b3_pw_fwd takes the launch: a single-tap, unit-stride, unpadded geometry whose output grid IS the input grid, without
@@ -198,4 +329,32 @@ int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bi
         case 7: return launch_pw<7, 2>(y, x, wplanes, bias, resid, p, stream);
         default: return launch_pw<8, 2>(y, x, wplanes, bias, resid, p, stream);
     }
+}
+
+// Weight gradient of the same flat geometry (no per-sample scales), Cin % 64 == 0 and Cout % 64 == 0.  IDEAS_B3_PW_WGRAD=0: never.
+int ideas_b3_pw_wgrad_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale) {
+    const char* e = getenv("IDEAS_B3_PW_WGRAD");
+    if (e && e[0] == '0') return 0;
+    if (in_scale || out_scale || p->reflect) return 0;
+    if (p->TY != 1 || p->TX != 1 || p->sy != 1 || p->sx != 1 || p->offy != 0 || p->offx != 0) return 0;
+    if (p->osy != 1 || p->osx != 1 || p->ooy != 0 || p->oox != 0) return 0;
+    if (p->OH != p->IH || p->OW != p->IW || p->YH != p->IH || p->YW != p->IW) return 0;
+    if (p->Cin % 64 || p->Cout % 64) return 0;
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    return M >= 512 && (M + 64) * p->Cin * 4 < 0xffffffffLL && (M + 64) * p->Cout * 4 < 0xffffffffLL;
+}
+
+int ideas_b3_pw_wgrad(float* gw, const void* gy, const void* x, const ideas_conv_params* p, hipStream_t stream) {
+    const int64_t M = (int64_t)p->B * p->OH * p->OW;
+    const int tiles_ci = p->Cin / 64, tiles = (p->Cout / 64) * tiles_ci;
+    // about four rounds of the 512 resident blocks, >= 256 pixels per range (multiples of the 32-pixel step)
+    int64_t ranges = 2048 / tiles;
+    if (ranges < 1) ranges = 1;
+    if (M / ranges < 256) ranges = M / 256 > 0 ? M / 256 : 1;
+    int64_t per = ideas_cdiv(ideas_cdiv(M, ranges), 32) * 32;
+    ranges = ideas_cdiv(M, per);
+    if ((int64_t)tiles * ranges > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    hipLaunchKernelGGL(conv_b3_pw_wgrad_kernel, dim3(splitk_grid(tiles, ranges)), dim3(256), 0, stream, gw, (const float*)gy,
+                       (const float*)x, *p, (unsigned)M, tiles_ci, tiles, (int)ranges, (unsigned)per);
+    return ideas_launch_status();
 }

@@ -639,6 +639,8 @@ extern "C" int ideas_conv_wgrad(float* gw, const void* gy, const void* x, const 
         return IDEAS_E_ALIGN;
     if ((int64_t)p->B * p->OH * p->OW >= 0x7fffffffLL) return IDEAS_E_SHAPE;
     hipStream_t stream = (hipStream_t)stream_;
+    if (dtype == IDEAS_F32_B3 && ideas_b3_pw_wgrad_ok(p, in_scale, out_scale))
+        return ideas_b3_pw_wgrad(gw, gy, x, p, stream);                          // 1x1 / stride 1: flat reduction over the pixels (conv_b3_pw.hip)
     if (dtype == IDEAS_F32_B3 && ideas_b3_wgrad3_enabled() && ideas_b3_wgrad3_supported(p))
         return ideas_b3_wgrad3(gw, gy, x, in_scale, out_scale, p, stream);      // 3x3: tap-fused, rolling window (conv_b3_wgrad3.hip)
     if (dtype == IDEAS_F32_B3 && ideas_b3_wgrad_supported(p)) return ideas_b3_wgrad(gw, gy, x, in_scale, out_scale, p, stream);

@@ -1347,6 +1347,31 @@ def test_pointwise_flat_gemm_kernel_is_bitwise_the_generic_kernel(case, monkeypa
         assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("case", [(2, 64, 128, 16, 16), (3, 128, 64, 9, 14), (1, 256, 128, 24, 24), (5, 512, 512, 8, 8), (2, 64, 64, 33, 17)])
+def test_pointwise_flat_weight_gradient_vs_float64(case, monkeypatch):
+    """The weight gradient of the 1x1 layers as a flat reduction over the pixels (csrc/conv_b3_pw.hip::conv_b3_pw_wgrad_kernel,
+    transpose reads on pixel-major planes) against f64 and against the generic split weight gradient (IDEAS_B3_PW_WGRAD=0); pixel
+    counts that are not multiples of the 32-pixel step or of a range, accumulation into an existing gradient."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    gy = torch.randn(B, co, H, W, dtype=torch.float64)
+    ref = torch.einsum("bohw,bihw->oi", gy, x).view(co, ci, 1, 1) * 0.13
+    g = ConvGeom(1, 1, 1, 0, False)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_B3_PW_WGRAD", flag)
+        outs.append(CV.conv_wgrad_raw(dev(gy.float(), True), dev(x.float(), True), g, (co, ci, 1, 1), 0.13))
+    assert rel_err(outs[0], ref) < GTOL and rel_err(outs[1], ref) < GTOL
+    assert rel_err(outs[0], outs[1]) < 5e-6
+    monkeypatch.setenv("IDEAS_B3_PW_WGRAD", "1")
+    acc = outs[0].clone()
+    CV.conv_wgrad_raw(dev(gy.float(), True), dev(x.float(), True), g, (co, ci, 1, 1), 0.13, out=acc)
+    assert rel_err(acc, 2 * ref) < GTOL
+
+
 # --------------------------------------------------------------------------------------------- EqualLinear on csrc/linear.hip
 @pytest.mark.parametrize("hip", [True, False])
 def test_equal_linear_golden(ops_golden, hip, monkeypatch):
