@@ -490,8 +490,15 @@ SINK_LOW_PRIORITY = _os.environ.get("IDEAS_SINK_PRIORITY", "default") == "low"
 
 
 class grad_sink:
-    def __init__(self, params):
+    """``defer=True``: leaving the context does NOT join the side stream; the caller does (``join()``) before it consumes the
+    gradients.  The D phase's weight gradients are wanted only by the discriminators' optimiser step, which the step defers to the
+    first discriminator call of the G phase (train_step._Deferred) -- until then they may keep running under the generator
+    forwards of the G phase instead of holding the main stream at the end of the backward pass."""
+
+    def __init__(self, params, defer: bool = False):
         self.ids = {id(p) for p in params if p.grad is not None and p.is_cuda}
+        self.defer = defer
+        self.pending = False
 
     def __enter__(self):
         if not self.ids:            # nothing to sink (no pre-existing device gradients): plain autograd
@@ -504,6 +511,14 @@ class grad_sink:
     def __exit__(self, *exc):
         if _SINK["ids"] is not None:
             _SINK["ids"] = None
+            if self.defer and exc[0] is None:
+                self.pending = True
+            else:
+                torch.cuda.current_stream().wait_stream(_SINK["stream"])
+
+    def join(self):
+        if self.pending:
+            self.pending = False
             torch.cuda.current_stream().wait_stream(_SINK["stream"])
 
 

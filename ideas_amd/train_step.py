@@ -39,6 +39,8 @@ NET_CLASSES = {
     "E": "DisentanglementEncoder", "G": "Generator", "Gstru": "StructureGenerator", "Ex": "TensorExtractor",
     "Dreal": "ImageLevelDiscriminator", "Dco": "CooccurenceDiscriminator", "Ddist": "DistributionDiscriminator",
 }
+import os as _os
+DEFER_SINK_JOIN = _os.environ.get("IDEAS_DEFER_SINK_JOIN", "1") != "0"     # A/B switch (see op/conv.py::grad_sink)
 EMA_NETS = ("E", "G", "Gstru", "Ex")
 G_SIDE = ("E", "G", "Gstru")
 D_SIDE = ("Dreal", "Dco", "Ddist")
@@ -222,8 +224,8 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         optimiser step): the all-reduce runs on RCCL's stream under whatever is issued in between.  Reducers without
         ``start`` (or no reducer) make it the plain blocking sequence at ``finish()``."""
 
-        def __init__(self, tag, params, opt, ema=True, refill=True):
-            self.tag, self.params, self.opt, self.ema, self.refill = tag, params, opt, ema, refill
+        def __init__(self, tag, params, opt, ema=True, refill=True, join=None):
+            self.tag, self.params, self.opt, self.ema, self.refill, self.join = tag, params, opt, ema, refill, join
             self.pending = reducer.start(tag, params) if (reducer is not None and hasattr(reducer, "start")) else None
             self.done = False
             pending_list.append(self)
@@ -239,6 +241,8 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
 
         def finish(self):
             try:
+                if self.join is not None:
+                    self.join()           # the gradient sink's side stream (weight gradients still in flight)
                 if self.pending is not None:
                     self.pending.wait()
                 elif reducer is not None:
@@ -254,6 +258,8 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
             if self.done:
                 return
             try:
+                if self.join is not None:
+                    self.join()
                 if self.pending is not None:
                     self.pending.wait()
             finally:
@@ -306,12 +312,14 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     losses["D_dist_loss"] = d_logistic_loss(T["Ddist"](T2), T["Ddist"](T1))
     d_total = d_total + losses["D_dist_loss"]
     T["d_optim"].zero_grad()
-    with grad_sink(d_params):
+    # (single process: the side stream's weight gradients are joined only in front of the deferred optimiser step, DEFER_SINK_JOIN)
+    d_sink = grad_sink(d_params, defer=DEFER_SINK_JOIN and reducer is None)
+    with d_sink:
         d_total.backward()
     # The D group's all-reduce starts here; the optimiser step that consumes it is deferred to the first use of a
     # discriminator: the R1 pass on lazy-regularisation iterations, otherwise the G phase's first Dreal call — so the
     # 182 MB exchange runs under the Gstru / G forwards of the G phase, which read no discriminator weight.
-    d_step = _Deferred("d", d_params, T["d_optim"])
+    d_step = _Deferred("d", d_params, T["d_optim"], join=d_sink.join)
     del fake_pred, real_pred, d_total, hat_X1, hat_X2, hat_X3
 
     # ------------------------------------------------------------------ lazy R1 (train.py:105-129)
