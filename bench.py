@@ -99,7 +99,7 @@ def roofline_probe_bf16(device, batch: int, launches: int):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     alg_bytes = 2.0 * batch * 256 * 256 * 128 * 2          # read x + write y, bf16
-    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "r04_pmc_bf16") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "r05_pmc_bf16") if batch == 32 else (None, None)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": note,
             "kernel": "conv_bf16_img_kernel<64,2,true> (the activation operand as an LDS image: one DMA of the 6 x 66 input pixels per 32-channel "
@@ -146,7 +146,7 @@ def roofline_probe(device, batch: int, launches: int):
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         b3w = CV.B3_WINO
         kname = "conv_b3_wino2d_kernel" if b3w else "conv_b3_kernel"
-        traffic, traffic_note = _pmc_traffic(kname, "r04_pmc_b3w" if b3w else "r04_pmc_b3") if batch == 32 else (None, None)
+        traffic, traffic_note = _pmc_traffic(kname, "r05_pmc_b3w" if b3w else "r05_pmc_b3") if batch == 32 else (None, None)
         executed = achieved * (4.0 if b3w else 6.0)       # bf16 MFMA FLOPs issued per algorithmic f32 FLOP
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -211,7 +211,7 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and (bf16 or (CV.MATH == _lib.F32_B3 and not CV.B3_WINO_WGRAD)):
-        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r04_pmc_bf16wg" if bf16 else "r04_pmc_b3wg")
+        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r05_pmc_bf16wg" if bf16 else "r05_pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, column strips x row ranges in "
             "XCD-banded order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
@@ -241,7 +241,7 @@ def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
     ms = e0.elapsed_time(e1) / launches
     nbytes = (batch * 128 * 256 * 256 + batch * 128 * 257 * 257) * (2 if bf16 else 4)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r04_pmc_blurbf16" if bf16 else "r04_pmc_blurf32", smallest_grid=True) if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r05_pmc_blurbf16" if bf16 else "r05_pmc_blurf32", smallest_grid=True) if batch == 32 else (None, None)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
             "traffic_source": note,
             "kernel": ("blur4_bf16x8_c2<0>" if bf16 else "blur4_f32_c2<0>") + " (4x4 FIR of a downsampling ConvLayer, two output columns per thread) on "
@@ -295,7 +295,7 @@ def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and not bf16 and CV.MATH == _lib.F32_B3:
-        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "r04_pmc_b3tp")
+        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "r05_pmc_b3tp")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on G.layers.7.conv1: stride-2 transposed 3x3 modconv 256->128, 128x128 -> 257x257, B=%d "
             "(all output-parity phases of the layer)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
@@ -338,7 +338,7 @@ def roofline_probe_s2(device, batch: int, launches: int):
     finally:
         conv_plan.cache_end()
     tf = lambda ms: round(flops / (ms * 1e-3) / 1e12, 2)
-    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false>", "r04_pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
+    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false>", "r05_pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
     alg = float(B3 * (256 * 256 + 128 * 128) * 128 * 4)
     return {"bound": "mfma", "achieved": tf(ms_f), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf(ms_f) / peak, 4), "traffic": traffic,
             "traffic_source": note,
@@ -644,6 +644,8 @@ def main():
             dist.destroy_process_group()
         return
     out = step_line(a, a.precision, res, world)
+    if res.get("roofline_weighted"):
+        out["roofline_weighted"] = res["roofline_weighted"]
     out["vs_rocm_eager"] = vs_rocm_eager(out["value"], a, world)
     if a.roofline == "on":
         out.update(rooflines(device, a.batch, a.roofline_launches, bf16))
@@ -656,6 +658,8 @@ def main():
         out["bf16"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "step_tflops", "step_frac_of_ceiling", "losses")}
         out["bf16"]["r1_steps_in_window"] = l2["config"]["r1_steps_in_window"]
         out["bf16"]["workload"] = l2["config"]["workload"]
+        if r2.get("roofline_weighted"):
+            out["bf16"]["roofline_weighted"] = r2["roofline_weighted"]
         if a.roofline == "on":
             out["bf16"]["roofline"] = roofline_probe_bf16(device, a.batch, a.roofline_launches)
     if a.cpu_baseline == "auto" and world == 1:
@@ -675,6 +679,25 @@ def rooflines(device, batch, launches, bf16):
             "roofline_direct": roofline_probe_direct(device, batch, launches, bf16),
             "roofline_hbm": roofline_probe_hbm(device, batch, launches, bf16),
             "roofline_hbm_bias_act_bwd": roofline_probe_bias_act_bwd(device, batch, launches, bf16)}
+
+
+def roofline_weighted(run_iteration, bf16: bool):
+    """the headline `roofline` object names ONE launch of ONE kernel; this one covers the step.  After the timed
+    window one more iteration is run with every libideas_hip.so launch timed in isolation (device synchronised around each call,
+    tools/step_census2.py) and grouped by family = entry point + kernel size / stride.  `frac` = the MFMA families' total ALGORITHMIC
+    FLOPs / their total isolated time / `peak` (the time-weighted mean of the per-family fractions); `families` lists each family's
+    share of the isolated step and its own fraction; `isolated_ms` is what the iteration costs with nothing overlapped."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import step_census2 as SC
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_BF16_MFMA_TFLOPS / 6.0
+    stats = SC.census(run_iteration)
+    rows, tot, ct, cf = SC.families(stats, peak)
+    return {"bound": "mfma", "achieved": round(cf / ct / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(cf / ct / 1e9 / peak, 4),
+            "what": "all MFMA convolution launches of one iteration (no lazy-R1 branch), each timed in isolation: total algorithmic FLOPs / "
+                    "total time; `families`: isolated ms, share of the isolated iteration, TFLOP/s and fraction per family (HBM-bound "
+                    "families have no fraction here: see roofline_hbm*)",
+            "isolated_ms": round(tot, 1), "mfma_ms": round(ct, 1), "launches": sum(v[0] for v in stats.values()),
+            "families": [r for r in rows if r["ms"] >= 0.5]}
 
 
 def run_steps(a, precision_name, steps, warmup, device, world, rank):
@@ -724,7 +747,12 @@ def run_steps(a, precision_name, steps, warmup, device, world, rank):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    res = {"dt": dt, "steps": steps, "warmup": warmup,
+    weighted = None
+    if getattr(a, "roofline", "off") == "on" and world == 1 and a.image_size == 256 and (a.channel, a.texture_channel) == (32, 2048):
+        idx = steps + 3
+        idx += 1 if idx % args.d_reg_every == 0 else 0                                   # (an iteration without the lazy-R1 branch)
+        weighted = roofline_weighted(lambda: step(idx), precision_name == "bf16")
+    res = {"dt": dt, "steps": steps, "warmup": warmup, "roofline_weighted": weighted,
            "n_r1": sum(1 for i in range(1, steps + 1) if i % args.d_reg_every == 0),
            "losses": {k: round(float(v.detach()), 4) for k, v in losses.items() if v.numel() == 1},
            "bucket_bytes": ({k: 4 * int(trainer[k].flat_g.numel()) for k in ("d_optim", "g_optim", "ex_optim") if hasattr(trainer[k], "flat_g")}
