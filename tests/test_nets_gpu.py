@@ -697,25 +697,36 @@ def test_full_width_gradients_vs_oracle(name, monkeypatch):
     oracle had no flip at all and sat at 2.6e-6) on different seeds of the SAME build.  A per-tensor ratio on one case is therefore
     a lottery ticket, not a measurement of kernel quality; the flip-free measurement is test_full_width_gradients_near_linear
     below (same networks, same kernels, activation slope 0.9999), which holds the kernels to 3x the f32 oracle.  Here the bar is the
-    error class: per tensor, L2 <= max(1e-4, 6 x f32 oracle) and max-abs <= max(1e-4 max|ref|, 12 x) on at least one of up to three
-    independent seeded cases, and never worse than 2e-2 (no flip moves a tensor that far; a wrong kernel does)."""
+    error class: per tensor, L2 <= max(1e-4, 6 x f32 oracle) and max-abs <= max(1e-4 max|ref|, 12 x) on at least one of three
+    independent seeded cases AND on the median of the three, and never worse than 2e-2 (no flip moves a tensor
+    that far; a wrong kernel does)."""
     def over(r):
         e_gpu, e_f32, l_gpu, l_f32 = r
         return max(l_gpu / max(GTOL, 6 * l_f32), e_gpu / max(GTOL, 12 * e_f32))
 
-    bad = None
-    for attempt, off in enumerate(("0", "10", "20")):
+    # Round 5 (VERDICT r4 item 7b): ALL three seeded cases are run and the bar is held twice -- per tensor on at least one case (as
+    # before: a flip on one case must not fail a correct kernel) AND on the MEDIAN over the three cases of the same excess ratio
+    # (a kernel that is wrong by a constant factor is over the bar on every case; a flip lottery is over it on a minority).  The
+    # median must meet the bar itself (MEDIAN_EXCESS = 1): measured medians sit at 0.02-0.23 of it (printed).
+    cases = []
+    for off in ("0", "10", "20"):
         monkeypatch.setenv("IDEAS_TEST_SEED_OFFSET", off)
         res = _full_width_grad_errors(name)
         for lab, r in res.items():
             assert r[2] <= 2e-2 and r[0] <= 5e-2, (name, lab, "not a flip: far outside the f32 error class", r)
         ratio = sorted(((r[2] / max(r[3], 1e-12), lab, r[2], r[3]) for lab, r in res.items() if r[2] > 1e-5), reverse=True)
         print(name, "case", off, "largest l2 ratio gpu / f32 oracle:", [(l, "%.1f" % q, "%.1e" % lg, "%.1e" % lf) for q, l, lg, lf in ratio[:6]])
-        now_bad = {lab for lab, r in res.items() if over(r) > 1.0}
-        bad = now_bad if bad is None else (bad & now_bad)
-        if not bad:
-            return
-    assert not bad, (name, "over the bar on all three seeded cases", sorted(bad))
+        cases.append({lab: over(r) for lab, r in res.items()})
+    labels = set(cases[0]) & set(cases[1]) & set(cases[2])
+    best = {lab: min(c[lab] for c in cases) for lab in labels}
+    med = {lab: sorted(c[lab] for c in cases)[1] for lab in labels}
+    worst_med = sorted(med.items(), key=lambda kv: -kv[1])[:5]
+    print(name, "median-of-three excess over the bar (1 = at the bar), worst tensors:", [(l, "%.2f" % v) for l, v in worst_med])
+    bad = sorted(lab for lab, v in best.items() if v > 1.0)
+    assert not bad, (name, "over the bar on all three seeded cases", bad)
+    MEDIAN_EXCESS = 1.0
+    bad_med = sorted(lab for lab, v in med.items() if v > MEDIAN_EXCESS)
+    assert not bad_med, (name, "median over the three seeded cases exceeds %.1f x the bar" % MEDIAN_EXCESS, [(l, med[l]) for l in bad_med])
 
 
 @pytest.mark.parametrize("name", ["E", "G", "Dreal", "Dco"])
