@@ -114,7 +114,7 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
 int ideas_b3_fwd_multi(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,
                        const ideas_conv_params* ps, hipStream_t stream);
 // conv_b3_pw.hip: 1x1 / stride-1 layers with Cin <= 128 as a flat HBM-bound GEMM (ideas_b3_pw_ok decides; same results as ideas_b3_fwd)
-int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale);
+int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale, const void* resid);
 int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bias, const void* resid, const ideas_conv_params* p,
                     hipStream_t stream);
 int ideas_b3_pw_wgrad_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale);

@@ -441,7 +441,7 @@ extern "C" int ideas_b3_conv_supported(const ideas_conv_params* p) {
 int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale,
                  const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
     // 1x1 layers with few input channels are bound by HBM, not by the matrix pipe: flat persistent GEMM (conv_b3_pw.hip)
-    if (ideas_b3_pw_ok(p, in_scale, out_scale)) return ideas_b3_pw_fwd(y, x, wplanes, bias, resid, p, stream);
+    if (ideas_b3_pw_ok(p, in_scale, out_scale, resid)) return ideas_b3_pw_fwd(y, x, wplanes, bias, resid, p, stream);
     // few pixels, many channels (E's texture head on 4x4 .. 7x7 maps, Dco's last blocks on 8B patches): 128 x 128 tiles are fewer
     // than the CUs -- the 64-channel N tile doubles the blocks (E.texture.1 forward 64 -> 128 blocks)
     const int64_t t128 = ideas_cdiv((int64_t)p->B * p->OH * p->OW, 128) * ideas_cdiv(p->Cout, 128);

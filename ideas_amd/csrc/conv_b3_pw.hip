@@ -170,6 +170,167 @@ int launch_pw(void* y, const void* x, const void* wplanes, const float* bias, co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same flat GEMM for MORE input channels (Cin a multiple of 128: 256 .. 1024): K no longer fits LDS at once, so a tile of 64
+// pixels walks K in chunks of 128 channels (one staging + one barrier pair per chunk, the next chunk's -- or the next tile's -- loads
+// in flight under the contraction), and the weight fragments come straight from L2 one K-step ahead of the MFMAs that use them.  A
+// block owns up to 256 output channels (two passes of 128 with their own accumulators; blockIdx.y = the 256-channel group), so the
+// x tile is staged once for all of them.  Same arithmetic and K order as the generic kernel: bitwise the same results.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NWC>
+__global__ __launch_bounds__(256, 2) void conv_b3_pwk_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                             const void* __restrict__ wplanes, const float* __restrict__ bias,
+                                                             const float* __restrict__ resid, ideas_conv_params p, unsigned M,
+                                                             unsigned plane_bytes, int ntiles, int nchunks) {
+    constexpr int KS = 8, CH = 128, MT = 2, BM = MT * 32;
+    constexpr int Q = CH / 4, NV = BM * Q / 256;     // 8 pieces per thread and chunk
+    constexpr int MTW = MT * NWC / 4;
+    constexpr int STEPB = BM * ROWB, PLANE = KS * STEPB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * PLANE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wc = wave % NWC, wr = wave / NWC;
+    const int ngrp0 = blockIdx.y * 256;              // first output channel of this block's group
+    const int npass = (p.Cout - ngrp0 + 32 * NWC - 1) / (32 * NWC) < 256 / (32 * NWC) ? (p.Cout - ngrp0 + 32 * NWC - 1) / (32 * NWC) : 256 / (32 * NWC);
+    const unsigned cin4 = (unsigned)p.Cin * 4u;
+    const unsigned x_bytes = M * cin4, y_bytes = M * (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)x_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wplanes, 0, (int)(3u * plane_bytes), (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)y_bytes, (int)RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)resid, 0, resid ? (int)y_bytes : 0, (int)RSRC_FLAGS);
+
+    // staging: piece f = t + 256 j of a chunk -> row f / 32, quad f % 32
+    int a_lds[NV];
+    unsigned a_off[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = t + 256 * j, row = f / Q, q = f - row * Q;
+        a_lds[j] = (q >> 2) * STEPB + row * ROWB + (((q & 3) * 8) ^ (((row >> 3) & 1) << 4));
+        a_off[j] = (unsigned)row * cin4 + (unsigned)q * 16u;
+    }
+    float4 pre[NV];
+    auto prefetch = [&](int tile, int c) {
+        const unsigned base = (unsigned)tile * (unsigned)BM * cin4 + (unsigned)c * (unsigned)(CH * 4);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const unsigned off = base + a_off[j];
+            pre[j] = buffer_load4(rx, off < x_bytes ? off : 0xffffffffu, 0);      // rows past M: zeros (a row's pieces are in or out together)
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const Split4 s = split4(pre[j]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(smem + a_lds[j] + pl * PLANE) = s.p[pl];
+        }
+    };
+    struct BF { bf16x8 f[3]; };
+    auto loadB = [&](BF& fb, int np, int kstep) {      // K-step kstep (of all of K) of this wave's 32 channels in pass np
+        const unsigned voff = (unsigned)((ngrp0 + np * (32 * NWC) + wc * 32 + li) * 32 + lh * 16);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            fb.f[pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                rw, (int)(voff + (unsigned)pl * plane_bytes), (int)((unsigned)kstep * (unsigned)p.Cout * 32u), 0));
+    };
+    const int f_off = (wr * MTW * 32 + li) * ROWB + ((lh ^ ((li >> 3) & 1)) << 4);
+
+    f32x16 acc[2][MTW];
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    prefetch(tile, 0);
+    for (;;) {
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int a = 0; a < MTW; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[np][a][e] = 0.f;
+        const int next = tile + gridDim.x;
+        for (int c = 0; c < nchunks; ++c) {
+            stage();
+            __syncthreads();
+            if (c + 1 < nchunks) prefetch(tile, c + 1);
+            else if (next < ntiles) prefetch(next, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                if (np < npass) {                        // uniform
+                    BF fb0, fb1;
+                    loadB(fb0, np, c * KS);
+#pragma unroll
+                    for (int s = 0; s < KS; s += 2) {
+                        loadB(fb1, np, c * KS + s + 1);
+                        {
+                            bf16x8 fa[MTW][3];
+#pragma unroll
+                            for (int a = 0; a < MTW; ++a)
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl)
+                                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(smem + pl * PLANE + s * STEPB + a * 32 * ROWB + f_off);
+#pragma unroll
+                            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                                for (int a = 0; a < MTW; ++a)
+                                    acc[np][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb0.f[PB[q]], acc[np][a], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s + 2 < KS) loadB(fb0, np, c * KS + s + 2);
+                        {
+                            bf16x8 fa[MTW][3];
+#pragma unroll
+                            for (int a = 0; a < MTW; ++a)
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl)
+                                    fa[a][pl] = *reinterpret_cast<const bf16x8*>(smem + pl * PLANE + (s + 1) * STEPB + a * 32 * ROWB + f_off);
+#pragma unroll
+                            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                                for (int a = 0; a < MTW; ++a)
+                                    acc[np][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[q]], fb1.f[PB[q]], acc[np][a], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            __syncthreads();                           // every wave is done reading the planes of this chunk
+        }
+        // ---- epilogue (conv_b3_pw_kernel's) ----
+        unsigned cout4 = (unsigned)p.Cout * 4u;
+        asm volatile("" : "+s"(cout4));
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+            const int n = ngrp0 + np * (32 * NWC) + wc * 32 + li;
+            if (np < npass && n < p.Cout) {
+                const float bv = bias ? bias[n] : 0.f;
+                const unsigned ybase = ((unsigned)tile * (unsigned)BM + (unsigned)(wr * MTW * 32 + 4 * lh)) * cout4 + (unsigned)n * 4u;
+#pragma unroll
+                for (int a = 0; a < MTW; ++a) {
+                    float rv[16];
+                    if (resid) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                rr, (int)ybase, (int)((unsigned)(a * 32 + (e & 3) + 8 * (e >> 2)) * cout4), 0));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = mul_rn(acc[np][a][e], p.gain);
+                        v = mul_then_add(v, 1.0f, bv);
+                        if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                        if (resid) v = (v + rv[e]) * p.resid_gain;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)ybase,
+                                                              (int)((unsigned)(a * 32 + (e & 3) + 8 * (e >> 2)) * cout4), 0);
+                    }
+                }
+            }
+        }
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same layers:  gw[o][ci] += gain * sum_m gy[m][o] * x[m][ci]  -- a reduction over ALL pixels of two flat
 // matrices, bound by reading them once.  conv_b3_wgrad.hip ran these at 10-110 TFLOP/s (its tiles stage 128 channels x 16 pixels per
 // 96 MFMAs with a register transpose; with one tap there is nothing to amortise that over).  Here, as in conv_b3_wgrad3.hip, the
@@ -303,15 +464,21 @@ __global__ __launch_bounds__(256, 2) void conv_b3_pw_wgrad_kernel(float* __restr
 }  // namespace
 
 // 1 when ideas_b3_pw_fwd takes the launch: a single-tap, unit-stride, unpadded geometry whose output grid IS the input grid, without
-// per-sample scales and without accumulation, 16 <= Cin <= 128 (Cin % 16 == 0), tensors below 4 GB.  IDEAS_B3_PW=0: never (A/B).
-int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale) {
+// per-sample scales and without accumulation, Cin % 16 == 0 up to 128 or Cin % 128 == 0 up to 1024, tensors below 4 GB.
+// IDEAS_B3_PW=0: never (A/B).
+int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale, const void* resid) {
     const char* e = getenv("IDEAS_B3_PW");
     if (e && e[0] == '0') return 0;
     if (in_scale || out_scale || p->accumulate || p->reflect) return 0;
     if (p->TY != 1 || p->TX != 1 || p->sy != 1 || p->sx != 1 || p->offy != 0 || p->offx != 0) return 0;
     if (p->osy != 1 || p->osx != 1 || p->ooy != 0 || p->oox != 0) return 0;
     if (p->OH != p->IH || p->OW != p->IW || p->YH != p->IH || p->YW != p->IW) return 0;
-    if (p->Cin % 16 || p->Cin < 16 || p->Cin > 128 || p->Cout < 16) return 0;
+    if (p->Cin % 16 || p->Cin < 16 || p->Cout < 16) return 0;
+    // more channels: chunks of 128 (conv_b3_pwk_kernel) -- where it wins.  Same box, tools/ab_pw.py: with the residual epilogue (the
+    // merge add of a skip branch, the gradient sum of a forked block input) 256 -> 512 @64x64 0.418 -> 0.271 ms, B96 @32x32 0.316 ->
+    // 0.203; without it the generic kernel is 7-9 % ahead on 256 -> 128, 512 -> 256 and 512 -> 512 (compute-heavier: its 128 x 128
+    // tile shares the staged pixels between more MFMAs), so those stay where they were.
+    if (p->Cin > 128 && (p->Cin % 128 || p->Cin > 1024 || !resid)) return 0;
     const int64_t M = (int64_t)p->B * p->OH * p->OW;
     // (+ one tile of slack on the x offsets: the prefetch of the last, partial tile computes offsets past M rows)
     return (M + 128) * p->Cin * 4 < 0xffffffffLL && M * p->Cout * 4 < 0xffffffffLL && (int64_t)p->Cin * p->Cout * 6 < 0xffffffffLL;
@@ -319,6 +486,20 @@ int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const floa
 
 int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bias, const void* resid, const ideas_conv_params* p,
                     hipStream_t stream) {
+    if (p->Cin > 128) {
+        const int64_t M = (int64_t)p->B * p->OH * p->OW;
+        const int64_t ntiles = ideas_cdiv(M, 64);
+        const unsigned plane_bytes = (unsigned)((int64_t)p->Cin * p->Cout * 2);
+        const unsigned ngrp = (unsigned)ideas_cdiv(p->Cout, 256);
+        const unsigned gx = (unsigned)(ntiles < 512 / ngrp ? ntiles : (512 / ngrp > 0 ? 512 / ngrp : 1));
+        if (p->Cout <= 64)
+            hipLaunchKernelGGL(conv_b3_pwk_kernel<2>, dim3(gx, ngrp), dim3(256), 0, stream, (float*)y, (const float*)x, wplanes, bias,
+                               (const float*)resid, *p, (unsigned)M, plane_bytes, (int)ntiles, p->Cin / 128);
+        else
+            hipLaunchKernelGGL(conv_b3_pwk_kernel<4>, dim3(gx, ngrp), dim3(256), 0, stream, (float*)y, (const float*)x, wplanes, bias,
+                               (const float*)resid, *p, (unsigned)M, plane_bytes, (int)ntiles, p->Cin / 128);
+        return ideas_launch_status();
+    }
     switch (p->Cin / 16) {
         case 1: return launch_pw<1, 4>(y, x, wplanes, bias, resid, p, stream);
         case 2: return launch_pw<2, 4>(y, x, wplanes, bias, resid, p, stream);

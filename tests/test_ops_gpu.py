@@ -1310,7 +1310,9 @@ def test_grad_sink_modulated_conv_and_linear(ops):
 
 # --------------------------------------------------------------------------------------------- 1x1 layers as a flat GEMM
 @pytest.mark.parametrize("case", [(2, 64, 128, 16, 16, "plain"), (3, 32, 64, 9, 14, "resid"), (1, 128, 256, 24, 8, "plain"), (2, 16, 48, 7, 5, "ba"),
-                                  (1, 96, 136, 10, 13, "resid"), (5, 128, 64, 8, 8, "ba"), (2, 112, 320, 6, 6, "plain"), (1, 80, 32, 33, 3, "resid")])
+                                  (1, 96, 136, 10, 13, "resid"), (5, 128, 64, 8, 8, "ba"), (2, 112, 320, 6, 6, "plain"), (1, 80, 32, 33, 3, "resid"),
+                                  (2, 256, 128, 16, 16, "resid"), (1, 512, 512, 9, 7, "resid"), (3, 384, 200, 5, 5, "resid"), (2, 256, 64, 8, 8, "resid"),
+                                  (1, 768, 320, 4, 4, "resid"), (2, 1024, 256, 3, 3, "resid")])    # last six: more than 128 input channels (K in chunks of 128; taken with the residual epilogue)
 def test_pointwise_flat_gemm_kernel_is_bitwise_the_generic_kernel(case, monkeypatch):
     """csrc/conv_b3_pw.hip (1x1 / stride-1 layers with Cin <= 128 as a persistent flat GEMM) against f64 and BITWISE against the
     generic split-bf16 kernel it replaces (IDEAS_B3_PW=0) -- forward, and the input gradient (the same kernel on the transposed
@@ -1338,7 +1340,8 @@ def test_pointwise_flat_gemm_kernel_is_bitwise_the_generic_kernel(case, monkeypa
         monkeypatch.setenv("IDEAS_B3_PW", flag)
         yy = CV.conv_fwd_raw(dev(x.float(), True), dev(w.float(), True), g, 0.11, bias=t(bias), act=bias is not None, act_gain=1.3,
                              alpha=0.2, resid=t(resid, True), resid_gain=0.7)
-        gg = CV.conv_dgrad_raw(dev(gy.float(), True), dev(w.float(), True), g, (H, W), 0.11) if co % 16 == 0 and co <= 128 else None
+        pw_dgrad = (co % 16 == 0 and co <= 128) or (co % 128 == 0 and co <= 1024)      # the input gradient contracts over Cout
+        gg = CV.conv_dgrad_raw(dev(gy.float(), True), dev(w.float(), True), g, (H, W), 0.11) if pw_dgrad else None
         outs.append((yy, gg))
     assert rel_err(outs[0][0], y) < TOL
     assert torch.equal(outs[0][0], outs[1][0]), (case, float((outs[0][0] - outs[1][0]).abs().max()))

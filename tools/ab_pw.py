@@ -16,7 +16,9 @@ def t(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 # B, Cin, Cout, R, resid
 for B, ci, co, R, rs in ((96, 64, 128, 128, True), (32, 128, 256, 128, True), (96, 128, 256, 64, True), (96, 128, 64, 128, False), (1024, 32, 64, 32, True),
-                         (1024, 64, 128, 16, True), (32, 64, 128, 128, True), (32, 32, 64, 128, True), (32, 128, 256, 64, False)):
+                         (1024, 64, 128, 16, True), (32, 64, 128, 128, True), (32, 32, 64, 128, True), (32, 128, 256, 64, False),
+                         (32, 256, 128, 128, False), (32, 512, 256, 64, False), (32, 256, 512, 64, True), (32, 512, 512, 32, False), (96, 256, 512, 32, True),
+                         (32, 512, 512, 16, False), (1024, 384, 256, 4, False)):
     gen = torch.Generator().manual_seed(1)
     x = torch.randn(B, ci, R, R, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
     w = torch.randn(co, ci, 1, 1, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
