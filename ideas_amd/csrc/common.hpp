@@ -119,6 +119,10 @@ int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bi
                     hipStream_t stream);
 int ideas_b3_pw_wgrad_ok(const ideas_conv_params* p, const float* in_scale, const float* out_scale);
 int ideas_b3_pw_wgrad(float* gw, const void* gy, const void* x, const ideas_conv_params* p, hipStream_t stream);
+// conv_b3_s2fir.hip, MODE 1: plain 3x3 / stride-2 / unpadded convs (optionally modulated) on the fused kernel's LDS image, no FIR
+int ideas_b3_s2img_ok(const ideas_conv_params* p, const float* in_scale);
+int ideas_b3_s2img_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale, const float* bias,
+                       const void* resid, const ideas_conv_params* p, hipStream_t stream);
 // conv_b3_tphase.hip: the four phases of a 3x3 / stride-2 / pad-0 transposed conv in one pass over a shared LDS image of the input
 // (-1: the launches are not that geometry -> conv_b3_multi_kernel)
 int ideas_b3_fwd_tphase(int n, void* y, const void* x, const void* const* wplanes, const float* in_scale, const float* out_scale,

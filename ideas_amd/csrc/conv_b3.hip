@@ -442,6 +442,8 @@ int ideas_b3_fwd(void* y, const void* x, const void* wplanes, const float* in_sc
                  const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream) {
     // 1x1 layers with few input channels are bound by HBM, not by the matrix pipe: flat persistent GEMM (conv_b3_pw.hip)
     if (ideas_b3_pw_ok(p, in_scale, out_scale, resid)) return ideas_b3_pw_fwd(y, x, wplanes, bias, resid, p, stream);
+    // 3x3 / stride 2 / no padding on a large grid: the LDS-image kernel stages every input pixel once per chunk instead of once per tap
+    if (ideas_b3_s2img_ok(p, in_scale)) return ideas_b3_s2img_fwd(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);
     // few pixels, many channels (E's texture head on 4x4 .. 7x7 maps, Dco's last blocks on 8B patches): 128 x 128 tiles are fewer
     // than the CUs -- the 64-channel N tile doubles the blocks (E.texture.1 forward 64 -> 128 blocks)
     const int64_t t128 = ideas_cdiv((int64_t)p->B * p->OH * p->OW, 128) * ideas_cdiv(p->Cout, 128);

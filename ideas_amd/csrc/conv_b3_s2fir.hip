@@ -66,12 +66,19 @@ constexpr int NPW = 4;                         // producer (FIR) waves: one per 
 
 // NCW: consumer (MFMA) waves, 4 or 8 (one or two per SIMD); WN of them along the channels (NCW / WN along the pixels), NB: 32-channel
 // blocks per consumer wave; N tile = WN * NB * 32.
-template <int NCW, int WN, int NB, bool XBOUT>
+// MODE 0: the producers blur (the kernel's purpose).  MODE 1 (round 5): NO FIR -- the producers only load, scale and split the 17 x 33
+// input pixels under the patch, i.e. a plain 3x3 / stride-2 convolution on the LDS-image layout (x IS the tensor p describes; f.XH = p.IH,
+// f.XW = p.IW, f.pad0 = 0), with the per-sample scales of a modulated conv (in_scale before the split, out_scale in the epilogue, the
+// order of conv_b3_kernel).  The generic kernel stages every input pixel once per TAP (nine times: 195-203 TFLOP/s on the input
+// gradients of G's upsampling layers); here it is staged once per chunk for all nine, and the consumer side is the one that runs
+// 297-304 TFLOP/s when nothing else is in its way.
+template <int NCW, int WN, int NB, bool XBOUT, int MODE = 0>
 __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(float* __restrict__ y, float* __restrict__ xb_out,
                                                                const float* __restrict__ x, const void* __restrict__ wplanes,
                                                                const float* __restrict__ bias, const float* __restrict__ resid,
                                                                ideas_conv_params p, S2Fir f, int tiles_n, unsigned x_bytes,
-                                                               unsigned plane_bytes, unsigned xb_bytes) {
+                                                               unsigned plane_bytes, unsigned xb_bytes,
+                                                               const float* __restrict__ in_scale, const float* __restrict__ out_scale) {
     constexpr int WM = NCW / WN, RB = 4 / WM;   // row blocks (32 pixels = 2 patch rows) per consumer wave
     constexpr int BN = WN * NB * 32;
     static_assert(RB == 1 || RB == 2 || RB == 4, "wave grid");
@@ -107,8 +114,11 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
         const int iy0 = 2 * oy0 - f.pad0, ix = 2 * ox0 - f.pad0 + j;  // raw pixel under (image row 0, column j), tap (0, 0)
         const unsigned cmask = (ix >= 0 && ix < f.XW) ? 0u : 0xffffffffu;      // raw column in the zero padding
         unsigned rbad = 0;                            // bit r: raw row iy0 + r lies in the zero padding; bit 24: side-output column not owned
+        // rows staged per chunk: the 20 raw rows under the 17 blurred ones, or (MODE 1) the 17 image rows + one dummy (18 = 2 x 9: the
+        // ring position of a row must not depend on the chunk)
+        constexpr int NROW = MODE == 0 ? RAWR : 18;
 #pragma unroll
-        for (int r = 0; r < RAWR; ++r) rbad |= ((iy0 + r >= 0 && iy0 + r < f.XH) ? 0u : 1u) << r;
+        for (int r = 0; r < NROW; ++r) rbad |= ((iy0 + r >= 0 && iy0 + r < f.XH && (MODE == 0 || r < IR)) ? 0u : 1u) << r;
         const unsigned colstep = (unsigned)p.Cin * 4u, rowstep = (unsigned)f.XW * colstep;
         // (mod 2^32: rows / columns left of the image give a wrapped offset, which its mask replaces)
         unsigned gbase = (unsigned)(((pb * f.XH + iy0) * f.XW + ix) * p.Cin + quad * 4) * 4u;
@@ -127,8 +137,8 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
         }
         const bool last_r = oy0 + TR >= p.OH;
 
-        constexpr int RING = 10, AHEAD = RING - 1;       // 20 rows per chunk: the ring position of a row is the same in every chunk
-        static_assert(RAWR % RING == 0 && RAWR % 4 == 0, "ring positions must not depend on the chunk");
+        constexpr int RING = MODE == 0 ? 10 : 9, AHEAD = RING - 1;       // 20 (18) rows per chunk: the ring position of a row is the same in every chunk
+        static_assert(NROW % RING == 0 && (MODE != 0 || RAWR % 4 == 0), "ring positions must not depend on the chunk");
         float4 ldv[RING];
         float4 h[4];                                     // horizontally filtered rows r - 3 .. r
         auto gload = [&](int r, int ci) {                // raw row r of the patch, chunk starting at channel ci
@@ -195,6 +205,18 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
             }
         };
 
+        // MODE 1: image row i = input row i: scale (rounded to f32 before the split, as conv_b3_kernel does), split, store
+        const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc((void*)in_scale, 0, (MODE == 1 && in_scale) ? p.B * p.Cin * 4 : 0, (int)RSRC_FLAGS);
+        auto emit_plain = [&](unsigned char* buf, int i, float4 sc) {
+            float4 v = ldv[i % RING];
+            if (in_scale) v = make_float4(mul_rn(v.x, sc.x), mul_rn(v.y, sc.y), mul_rn(v.z, sc.z), mul_rn(v.w, sc.w));
+            const Split4 s_ = split4(v);
+            if (on) {
+                unsigned char* a = buf + ((i & 1) ? (w0 ^ 16) : w0) + i * PITCH * ROWB;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(a + pl * PLB) = s_.p[pl];
+            }
+        };
 #pragma unroll
         for (int r = 0; r < AHEAD; ++r) gload(r, 0);
         for (int c = 0; c < nc; ++c) {
@@ -204,14 +226,26 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
             // (opaque to the optimizer: nothing derived from these is hoisted out of the chunk loop)
             asm volatile("" : "+v"(gbase), "+v"(rbad), "+v"(w0));
             if (XBOUT) asm volatile("" : "+v"(xb_off));
+            if constexpr (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < RAWR; ++r) {
-                if (S2FIR_ABL == 1) break;
-                if (S2FIR_ABL != 3) { if (r + AHEAD < RAWR) gload(r + AHEAD, ci); else gload(r + AHEAD - RAWR, ci_next); }
-                SB;
-                hrow(r);
-                if (r >= 3) emit(buf, r - 3, ci);
-                SB;
+                for (int r = 0; r < RAWR; ++r) {
+                    if (S2FIR_ABL == 1) break;
+                    if (S2FIR_ABL != 3) { if (r + AHEAD < RAWR) gload(r + AHEAD, ci); else gload(r + AHEAD - RAWR, ci_next); }
+                    SB;
+                    hrow(r);
+                    if (r >= 3) emit(buf, r - 3, ci);
+                    SB;
+                }
+            } else {
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (in_scale) sc = buffer_load4(rsi, (unsigned)(pb * p.Cin + ci + quad * 4) * 4u, 0);
+#pragma unroll
+                for (int r = 0; r < NROW; ++r) {
+                    if (r + AHEAD < NROW) gload(r + AHEAD, ci); else gload(r + AHEAD - NROW, ci_next);
+                    SB;
+                    if (r < IR) emit_plain(buf, r, sc);
+                    SB;
+                }
             }
             __syncthreads();                             // image of chunk c complete; the consumers are done with chunk c - 1
         }
@@ -316,6 +350,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
         const int n = n0 + (wn * NB + nb) * 32 + li;
         if (n >= p.Cout) continue;
         const float bv = bias ? bias[n] : 0.f;
+        const float osv = (MODE == 1 && out_scale) ? out_scale[(int64_t)pb * p.Cout + n] : 1.f;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -325,6 +360,7 @@ __global__ __launch_bounds__((NCW + NPW) * 64, 1) void conv_b3_s2fir_kernel(floa
                 if (oy >= p.OH || ox >= p.OW) continue;
                 const int64_t off = (((int64_t)pb * p.YH + oy) * p.YW + ox) * p.Cout + n;
                 float v = mul_rn(acc[rb][nb][e], p.gain);
+                if (MODE == 1 && out_scale) v = mul_rn(v, osv);
                 v = mul_then_add(v, 1.0f, bv);
                 if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
                 if (resid) v = (v + resid[off]) * p.resid_gain;
@@ -345,10 +381,29 @@ int launch_s2fir(void* y, void* xb, const void* x, const void* wplanes, const fl
     const unsigned plane_bytes = (unsigned)((int64_t)9 * p->Cin * p->Cout * 2);
     if (xb)
         hipLaunchKernelGGL((conv_b3_s2fir_kernel<NCW, WN, NB, true>), dim3((unsigned)(tm * tn)), dim3((NCW + NPW) * 64), 0, stream, (float*)y, (float*)xb,
-                           (const float*)x, wplanes, bias, (const float*)resid, *p, f, tn, x_bytes, plane_bytes, xb_bytes);
+                           (const float*)x, wplanes, bias, (const float*)resid, *p, f, tn, x_bytes, plane_bytes, xb_bytes, (const float*)nullptr,
+                           (const float*)nullptr);
     else
         hipLaunchKernelGGL((conv_b3_s2fir_kernel<NCW, WN, NB, false>), dim3((unsigned)(tm * tn)), dim3((NCW + NPW) * 64), 0, stream, (float*)y, (float*)xb,
-                           (const float*)x, wplanes, bias, (const float*)resid, *p, f, tn, x_bytes, plane_bytes, xb_bytes);
+                           (const float*)x, wplanes, bias, (const float*)resid, *p, f, tn, x_bytes, plane_bytes, xb_bytes, (const float*)nullptr,
+                           (const float*)nullptr);
+    return ideas_launch_status();
+}
+
+template <int NCW, int WN, int NB>
+int launch_s2img(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale, const float* bias, const void* resid,
+                 const ideas_conv_params* p, hipStream_t stream) {
+    constexpr int BN = WN * NB * 32;
+    const int64_t tm = (int64_t)p->B * ideas_cdiv(p->OH, TR) * ideas_cdiv(p->OW, TP);
+    const int tn = (int)ideas_cdiv(p->Cout, BN);
+    if (tm * tn > 0x7fffffffLL) return IDEAS_E_SHAPE;
+    S2Fir f;
+    for (int i = 0; i < 4; ++i) f.kh[i] = f.kv[i] = 0.f;
+    f.XH = p->IH; f.XW = p->IW; f.pad0 = 0;
+    const unsigned x_bytes = (unsigned)((int64_t)p->B * p->IH * p->IW * p->Cin * 4);
+    const unsigned plane_bytes = (unsigned)((int64_t)9 * p->Cin * p->Cout * 2);
+    hipLaunchKernelGGL((conv_b3_s2fir_kernel<NCW, WN, NB, false, 1>), dim3((unsigned)(tm * tn)), dim3((NCW + NPW) * 64), 0, stream, (float*)y, (float*)nullptr,
+                       (const float*)x, wplanes, bias, (const float*)resid, *p, f, tn, x_bytes, plane_bytes, 0u, in_scale, out_scale);
     return ideas_launch_status();
 }
 
@@ -390,4 +445,32 @@ extern "C" int ideas_b3_blur_conv_s2(void* y, void* xb_out, const void* x, const
                                    : launch_s2fir<4, 4, 1>(y, xb_out, x, wplanes, bias, resid, p, f, stream);    //      1 x 4 waves of 128 x 32
     return eight ? launch_s2fir<8, 2, 1>(y, xb_out, x, wplanes, bias, resid, p, f, stream)                       // 64:  4 x 2 waves of 32 x 32
                  : launch_s2fir<4, 2, 1>(y, xb_out, x, wplanes, bias, resid, p, f, stream);                      //      2 x 2 waves of 64 x 32
+}
+
+// The same LDS-image kernel WITHOUT the FIR (MODE 1): a plain 3x3 / stride-2 / unpadded convolution, optionally modulated.  Taken by
+// ideas_b3_fwd for grids of at least IDEAS_S2IMG_MIN_BLOCKS patches x N tiles (default 512 = two per CU; 0 in the environment: never).
+int ideas_b3_s2img_ok(const ideas_conv_params* p, const float* in_scale) {
+    const char* e = getenv("IDEAS_S2IMG_MIN_BLOCKS");
+    const int64_t minb = e ? atoll(e) : 512;
+    if (minb <= 0) return 0;
+    if (p->TY != 3 || p->TX != 3 || p->sy != 2 || p->sx != 2 || p->dy != 1 || p->dx != 1 || p->offy != 0 || p->offx != 0) return 0;
+    if (p->osy != 1 || p->osx != 1 || p->ooy != 0 || p->oox != 0 || p->YH != p->OH || p->YW != p->OW || p->reflect || p->accumulate) return 0;
+    if (p->OH != (p->IH - 3) / 2 + 1 || p->OW != (p->IW - 3) / 2 + 1 || p->IH < 3 || p->IW < 3) return 0;
+    if (p->Cin % 16 || p->Cout % 4 || p->OW < 16 || p->OH < 8) return 0;
+    // Where it wins (tools/ab_s2img.py, same box, against conv_b3_kernel): the 256-channel N tile with eight consumer waves -- the
+    // modulated input gradients of G's upsampling layers 190.9 -> 204.4, 205.3 -> 219.4, 195.8 -> 218.7 TFLOP/s; unmodulated 512 -> 512
+    // 217 -> 227.  One 128- or 64-channel N tile amortises the staging of a patch over too few MFMAs (128 -> 128: 191 -> 166, 64 -> 64:
+    // 121 -> 99) and 256 -> 256 is a tie: those keep the generic kernel.  (IDEAS_S2IMG_ALL=1: every shape the kernel covers -- tests.)
+    const char* ea = getenv("IDEAS_S2IMG_ALL");
+    if (!(ea && ea[0] == '1') && !(p->Cout > 128 && (in_scale || p->Cin >= 512))) return 0;
+    const int nt = p->Cout > 128 ? 256 : p->Cout > 64 ? 128 : 64;
+    if ((int64_t)p->B * ideas_cdiv(p->OH, TR) * ideas_cdiv(p->OW, TP) * ideas_cdiv(p->Cout, nt) < minb) return 0;
+    return (int64_t)p->B * p->IH * p->IW * p->Cin * 4 < 0xffffffffLL && (int64_t)9 * p->Cin * p->Cout * 6 < 0xffffffffLL;
+}
+
+int ideas_b3_s2img_fwd(void* y, const void* x, const void* wplanes, const float* in_scale, const float* out_scale, const float* bias,
+                       const void* resid, const ideas_conv_params* p, hipStream_t stream) {
+    if (p->Cout > 128) return launch_s2img<8, 8, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);
+    if (p->Cout > 64) return launch_s2img<4, 4, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);
+    return launch_s2img<4, 2, 1>(y, x, wplanes, in_scale, out_scale, bias, resid, p, stream);
 }

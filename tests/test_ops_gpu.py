@@ -1675,6 +1675,43 @@ def test_blur_conv_s2_vs_oracle(case):
         assert rel_err(yd, y2) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 33, 33, "plain"), (1, 128, 128, 65, 65, "mod"), (2, 64, 256, 17, 33, "ba"), (1, 16, 320, 35, 49, "mod"),
+                                  (3, 256, 128, 33, 65, "resid"), (1, 48, 36, 41, 71, "mod")])
+def test_stride2_lds_image_kernel_is_bitwise_the_generic_kernel(case, monkeypatch):
+    """The fused Blur + stride-2 kernel WITHOUT its FIR (csrc/conv_b3_s2fir.hip, MODE 1: a plain 3x3 / stride-2 / unpadded conv whose
+    input patch is staged once per 16-channel chunk for all nine taps) against f64 and BITWISE against the generic split kernel it
+    replaces on large grids (IDEAS_S2IMG_MIN_BLOCKS=0 disables it): plain, with the per-sample scales of a modulated conv (the input
+    gradient of G's upsampling layers, stylegan2/model.py:250-261), bias + leaky-ReLU, the residual epilogue; odd and even output
+    sizes, partial patches, all three channel tiles."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, kind = case
+    torch.manual_seed(sum(case[:5]))
+    x = torch.randn(B, ci, H, W, dtype=torch.float64)
+    w = torch.randn(co, ci, 3, 3, dtype=torch.float64)
+    ins = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if kind == "mod" else None
+    outs_ = (torch.rand(B, co, dtype=torch.float64) + 0.5) if kind == "mod" else None
+    bias = torch.randn(co, dtype=torch.float64) * 0.3 if kind == "ba" else None
+    y = F.conv2d(x * ins.view(B, ci, 1, 1) if ins is not None else x, w * 0.05, stride=2)
+    if outs_ is not None:
+        y = y * outs_.view(B, co, 1, 1)
+    if bias is not None:
+        y = F.leaky_relu(y + bias.view(1, -1, 1, 1), 0.2) * 1.2
+    resid = torch.randn_like(y) if kind == "resid" else None
+    if resid is not None:
+        y = (y + resid) * 0.6
+    g = ConvGeom(3, 3, 2, 0, False)
+    t = lambda v, cl=False: None if v is None else dev(v.float(), cl)
+    res = []
+    monkeypatch.setenv("IDEAS_S2IMG_ALL", "1")              # every shape the kernel covers, not only those where it is the faster one
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_S2IMG_MIN_BLOCKS", flag)
+        res.append(CV.conv_fwd_raw(dev(x.float(), True), dev(w.float(), True), g, 0.05, lin=t(ins), lout=t(outs_), bias=t(bias), act=bias is not None,
+                                   act_gain=1.2, alpha=0.2, resid=t(resid, True), resid_gain=0.6))
+    assert rel_err(res[0], y) < TOL
+    assert torch.equal(res[0], res[1]), (case, float((res[0] - res[1]).abs().max()))
+
+
 def test_blur_conv_s2_dpp_builtin_build_is_bitwise_too():
     """the producer's horizontal taps are hand-written v_fmac_f32_dpp assembly whose wait states the compiler's hazard
     recogniser cannot see.  csrc/Makefile also builds libideas_hip_dppb.so with those taps from __builtin_amdgcn_update_dpp + fmaf
