@@ -251,9 +251,10 @@ def cached(w: torch.Tensor, key, make, prep=None):
 # gradients' packs), so an evicting policy -- FIFO or LRU alike -- drops exactly the entries the next pass asks for once the working
 # set exceeds the budget.  Admission control instead: entries are admitted until the budget is full and then stay for
 # the iteration (hit rate = budget / working set, never zero); a miss beyond the budget is made, used and dropped by its caller.
-# B = 32 at 256x256: 1.2 GB of forward packs + 1.2 GB of input-gradient packs per recurring style (T1), the same again for T2 of the
-# G phase -> 4 GB keeps both (of 288 GB); BUDGET_STATS counts what happened (tools/probes/pack_cache_stats.py).
-STYLE_BUDGET_MB = int(_os.environ.get("IDEAS_STYLE_BUDGET_MB", "4096"))
+# B = 32 at 256x256 the packs of one iteration peak at 5.8 GB (of 288 GB): the default of 8 GB admits all of them -- measured per
+# iteration (tools/probes/pack_cache_stats.py): 70 hits / 113 admitted / 0 rejected, against 54 / 91 / 38 at 4 GB; bf16 step 153.4 ->
+# 152.0 ms, same box.  BUDGET_STATS counts what happened.
+STYLE_BUDGET_MB = int(_os.environ.get("IDEAS_STYLE_BUDGET_MB", "8192"))
 _BUDGETED = {}      # cache key -> bytes of the admitted entries still in _CACHE
 _BUDGET_TOTAL = [0]
 BUDGET_STATS = {"hit": 0, "admitted": 0, "rejected": 0, "peak_bytes": 0}
