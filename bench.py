@@ -338,7 +338,7 @@ def roofline_probe_s2(device, batch: int, launches: int):
     finally:
         conv_plan.cache_end()
     tf = lambda ms: round(flops / (ms * 1e-3) / 1e12, 2)
-    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false>", "r05_pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
+    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false,", "r05_pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
     alg = float(B3 * (256 * 256 + 128 * 128) * 128 * 4)
     return {"bound": "mfma", "achieved": tf(ms_f), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf(ms_f) / peak, 4), "traffic": traffic,
             "traffic_source": note,
