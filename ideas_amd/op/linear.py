@@ -16,7 +16,6 @@ gradient) the products run on ``torch.addmm`` -- a library GEMM, spelled with di
 """
 from __future__ import annotations
 
-import ctypes as C
 import os
 from typing import List, Optional, Sequence, Tuple
 

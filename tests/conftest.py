@@ -23,9 +23,6 @@ def _ensure_built():
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
-os.environ.setdefault("IDEAS_B3_WGRAD3_S2", "1")      # (the default since round 4: the stride-2 path of csrc/conv_b3_wgrad3.hip)
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _ensure_built()

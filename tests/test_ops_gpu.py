@@ -970,7 +970,18 @@ WGRAD3_CASES = [
     (2, 128, 128, 32, 32, 2, False, True),     # stride 2, modulated (roles as in the upsampling modulated conv's weight gradient)
     (1, 192, 64, 64, 64, 1, False, False),     # long ranges cut inside one image (range boundaries are not image boundaries)
     (7, 64, 64, 16, 32, 1, False, False),      # rows_total = 112 not a multiple of the range length
+    (1, 64, 64, 64, 48, 2, False, False),      # stride 2: three strips, ranges cut inside the image
+    (3, 64, 128, 16, 32, 2, False, True),      # stride 2, modulated, three images per range (scales and window change together)
+    (2, 64, 64, 16, 16, 2, True, False),       # stride 2 with one pixel of mirror padding (input 2H-1)
 ]
+
+
+@pytest.mark.parametrize("case", [c for c in WGRAD3_CASES if c[5] == 2])
+def test_b3_tap_fused_weight_gradient_stride2_two_rows_per_step(case, monkeypatch):
+    """IDEAS_B3_WGRAD3_S2=2: the stride-2 cases on conv_b3_wgrad3_s2pair_kernel (two window rows and one barrier per output row, ring
+    of five rows; measured at parity with the default one-row kernel and kept opt-in)."""
+    monkeypatch.setenv("IDEAS_B3_WGRAD3_S2", "2")
+    test_b3_tap_fused_weight_gradient(case)
 
 
 @pytest.mark.parametrize("case", WGRAD3_CASES)
@@ -984,8 +995,8 @@ def test_b3_tap_fused_weight_gradient(case):
     from ideas_amd.op.conv_plan import ConvGeom, plan_wgrad
     B, ci, co, OH, OW, st, refl, scaled = case
     torch.manual_seed(sum(case[:6]))
-    pd = 1 if st == 1 else 0
-    H, W = (OH, OW) if st == 1 else (2 * OH + 1, 2 * OW + 1)
+    pd = 1 if (st == 1 or refl) else 0
+    H, W = (OH, OW) if st == 1 else (2 * OH + 1 - 2 * pd, 2 * OW + 1 - 2 * pd)
     x = torch.randn(B, ci, H, W, dtype=torch.float64) * (torch.rand(B, ci, 1, 1, dtype=torch.float64) * 3 + 0.1)
     w = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
     s = (torch.rand(B, ci, dtype=torch.float64) + 0.5) if scaled else None
@@ -1005,7 +1016,7 @@ def test_b3_tap_fused_weight_gradient(case):
     (gw_abs,) = torch.autograd.grad(fwd(x.abs(), wa), wa, gy.abs())          # sum |gy * x| per weight
     g = ConvGeom(3, 3, st, pd, refl)
     p = CV._params(plan_wgrad(x.shape, y.shape, g), gain)
-    # (stride 2: the default since round 4, IDEAS_B3_WGRAD3_S2=0 switches it off)
+    # (stride 2: the default since round 4, IDEAS_B3_WGRAD3_S2=0 switches it off, =2 takes the two-rows-per-step kernel)
     assert _lib.load().ideas_b3_wgrad3_supported(C.byref(p)) == 1, case
     xd, gyd = dev(x.float(), True), dev(gy.float(), True)
     sd = dev(s.float()) if scaled else None
