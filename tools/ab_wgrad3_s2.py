@@ -8,6 +8,7 @@ from ideas_amd.op import conv as CV
 from ideas_amd.op.conv_plan import ConvGeom
 dev = torch.device("cuda")
 g2 = ConvGeom(3, 3, 2, 0, False)
+g1 = ConvGeom(3, 3, 1, 1, False)
 def t(fn, reps=8):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -37,3 +38,14 @@ for B, ci, co, R, mod in ((32, 128, 256, 257, True), (32, 256, 512, 129, True), 
     a, b = min(res["1"]), min(res["2"])
     dif = float((out["1"] - out["2"]).abs().max() / out["1"].abs().max())
     print(f"B{B:4d} {ci:3d}->{co:3d} @{R:3d} mod={int(mod)}  one row {a:6.3f} ms {flops / a / 1e9:6.1f} TF | pair {b:6.3f} ms {flops / b / 1e9:6.1f} TF | x{a / b:4.2f}  max diff {dif:.1e}")
+# stride-1 shapes of the step on the same kernel family (one timing each; IDEAS_HIP_LIB selects a probe library, tools/probes/w3_nosplit.sh)
+for B, ci, co, R, mod in ((32, 128, 128, 256, True), (32, 256, 256, 128, True), (32, 512, 512, 64, True), (96, 128, 128, 256, False), (96, 512, 512, 32, False)):
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(B, ci, R, R, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, co, R, R, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
+    s = (torch.rand(B, ci, generator=gen) + 0.5).to(dev) if mod else None
+    d = (torch.rand(B, co, generator=gen) + 0.5).to(dev) if mod else None
+    acc = torch.zeros(co, ci, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    flops = 2.0 * B * R * R * ci * co * 9
+    a = min(t(lambda: CV.conv_wgrad_raw(gy, x, g1, (co, ci, 3, 3), 0.05, lin=s, lout=d, out=acc)) for _ in range(2))
+    print(f"B{B:4d} {ci:3d}->{co:3d} @{R:3d} mod={int(mod)}  stride 1 {a:6.3f} ms {flops / a / 1e9:6.1f} TF")
