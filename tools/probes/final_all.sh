@@ -7,5 +7,6 @@ PRECISION=bf16 python tools/step_census2.py > gpurun_out/r05_bf16_step_census.tx
 python tools/ab_pw.py > gpurun_out/r05_pointwise_ab.txt 2>&1
 python tools/ab_wino_epi.py > gpurun_out/r05_wino_epilogue_ab.txt 2>&1
 python tools/ab_s2img.py > gpurun_out/r05_s2img_ab.txt 2>&1
+python tools/ab_wgrad3_s2.py > gpurun_out/r05_wgrad3_s2_ab.txt 2>&1
 python tools/probes/pack_cache_stats.py > gpurun_out/r05_pack_cache_stats.txt 2>&1
 ls gpurun_out | head -40
