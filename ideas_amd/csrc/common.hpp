@@ -144,6 +144,10 @@ int ideas_b3_wino_wgrad(float* gu, const void* gy, const void* x, const float* i
 // conv_bf16.hip: bf16 mixed-precision family (dtype IDEAS_BF16): bf16 activations, packed bf16 weights (ideas_bf16_pack_weights)
 int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                    const void* resid, const ideas_conv_params* p, hipStream_t stream);
+// conv_bf16_pw.hip: 1x1 / stride-1 layers with 32 / 64 / 128 input channels as a flat HBM-bound GEMM (ideas_bf16_pw_ok decides; same results)
+int ideas_bf16_pw_ok(const ideas_conv_params* p, int per_image, const float* out_scale, const void* y, const void* resid);
+int ideas_bf16_pw_fwd(void* y, const void* x, const void* wpack, const float* bias, const void* resid, const ideas_conv_params* p,
+                      hipStream_t stream);
 int ideas_bf16_fwd_multi(int n, void* y, const void* x, const void* const* wpack, int per_image, const float* out_scale,
                          const ideas_conv_params* ps, hipStream_t stream);
 int ideas_bf16_wgrad(float* gw, const void* gy, const void* x, const float* in_scale, const float* out_scale,

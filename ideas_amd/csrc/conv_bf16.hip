@@ -1104,6 +1104,7 @@ int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, con
     // 8-wave 256 x 128 tile is 8-10 % ahead of the 4-wave 128 x 128 tile (0.375 instead of 0.5 DMA pieces per MFMA), 256 x 256 adds
     // 1-3 % on 512-channel layers only and loses badly below; a fourth LDS stage and a register-prefetch pipeline (fragments of
     // tile t+1 read under the MFMAs of tile t) both measured 3-5 % SLOWER than three stages + counted vmcnt.
+    if (ideas_bf16_pw_ok(p, per_image, out_scale, y, resid)) return ideas_bf16_pw_fwd(y, x, wpack, bias, resid, p, stream);   // flat 1x1 (conv_bf16_pw.hip)
     const int64_t rows = (int64_t)(per_image ? 1 : p->B) * p->OH * p->OW;
     if (const int tp = bf16_img_tp(p)) {                  // 3x3 / stride 1: the activation operand as an LDS image (IDEAS_BF16_IMG=0: off)
         if (p->Cout > 64) return launch_bf16_img_tp<2>(tp, y, x, wpack, per_image, out_scale, bias, resid, p, stream);

@@ -14,7 +14,9 @@
  *   - no global state, no allocation, no host synchronisation: every call only enqueues on `stream`.  The only thing a call reads
  *     besides its arguments is a handful of A/B measurement switches in the process environment, looked up PER CALL (nothing is
  *     cached in the library): IDEAS_B3_WINO2D, IDEAS_B3_TPHASE, IDEAS_B3_WGRAD3, IDEAS_B3_WGRAD3_S2, IDEAS_S2FIR_CFG,
- *     IDEAS_BF16_IMG, IDEAS_BF16_WGRAD3 -- each "0" selects the older kernel of its family, unset = the default dispatch.
+ *     IDEAS_BF16_IMG, IDEAS_BF16_WGRAD3, IDEAS_B3_PW, IDEAS_B3_PW_WGRAD, IDEAS_BF16_PW, IDEAS_B3_WINO_EPI, IDEAS_S2IMG_MIN_BLOCKS
+ *     -- each "0" selects the older kernel of its family, unset = the default dispatch (IDEAS_B3_WGRAD3_S2=2: the opt-in
+ *     two-rows-per-step variant).
  *     What IS memoised per process: immutable device properties (the CU count and the occupancy hipOccupancy... reports for the
  *     library's own split-K kernels), used to size grids;
  *   - return value: 0 = enqueued; negative = argument error (IDEAS_E_*); positive = hipError_t of the launch.

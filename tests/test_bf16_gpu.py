@@ -105,6 +105,51 @@ def test_conv_bf16_vs_f64_on_rounded_operands(ops, bf16_mode, case):
     assert rel_err(gwd, gw) < 1e-3, ("gw", case, rel_err(gwd, gw))
 
 
+PW_BF16_CASES = [
+    # B, Cin, Cout, H, W, epilogue         (csrc/conv_bf16_pw.hip: Cin 32 / 64 / 128, Cout % 8 == 0 up to 256)
+    (2, 64, 128, 16, 16, "resid"), (3, 128, 256, 9, 14, "resid"), (1, 32, 64, 24, 24, "resid"), (2, 128, 64, 33, 17, "plain"),
+    (5, 64, 64, 8, 8, "ba"), (2, 32, 256, 7, 9, "plain"), (1, 128, 200, 12, 20, "ba"), (2, 64, 72, 5, 13, "resid"), (3, 128, 128, 16, 24, "ba_resid"),
+    (1, 64, 8, 40, 40, "plain"), (2, 32, 136, 11, 11, "ba"),
+]
+
+
+@pytest.mark.parametrize("case", PW_BF16_CASES)
+def test_pointwise_flat_kernel_bf16_is_bitwise_the_generic_kernel(case, monkeypatch):
+    """csrc/conv_bf16_pw.hip (1x1 / stride-1 layers with 32 / 64 / 128 input channels as a persistent flat GEMM: whole pixel rows by
+    LDS-DMA, weights resident in registers, one barrier per tile behind a counted vmcnt wait) against f64 on the bf16-rounded operands
+    and BITWISE against the generic bf16 kernel it replaces (IDEAS_BF16_PW=0) -- forward, and the input gradient (the same kernel on
+    the transposed weights) where its channel counts qualify; ragged last tiles, one and two passes over the output channels, channel
+    counts that end inside a 32-channel block, bias + leaky-ReLU, the residual epilogue and both together."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    B, ci, co, H, W, kind = case
+    torch.manual_seed(sum(case[:5]))
+    x = bf(torch.randn(B, ci, H, W, dtype=torch.float64))
+    w = bf(torch.randn(co, ci, 1, 1, dtype=torch.float64))
+    bias = torch.randn(co, dtype=torch.float64).float().double() * 0.3 if kind.startswith("ba") else None
+    resid = bf(torch.randn(B, co, H, W, dtype=torch.float64)) if kind.endswith("resid") else None
+    y = F.conv2d(x, w * 0.11)
+    if bias is not None:
+        y = F.leaky_relu(y + bias.view(1, -1, 1, 1), 0.2) * 1.3
+    if resid is not None:
+        y = (y + resid) * 0.7
+    gy = bf(torch.randn(B, co, H, W, dtype=torch.float64))
+    gx = F.conv_transpose2d(gy, w * 0.11)
+    g = ConvGeom(1, 1, 1, 0, False)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IDEAS_BF16_PW", flag)
+        yy = CV.conv_fwd_raw(dev(x, dtype=BF), dev(w.float()), g, 0.11, bias=None if bias is None else dev(bias.float()), act=bias is not None,
+                             act_gain=1.3, alpha=0.2, resid=None if resid is None else dev(resid, dtype=BF), resid_gain=0.7)
+        gg = CV.conv_dgrad_raw(dev(gy, dtype=BF), dev(w.float()), g, (H, W), 0.11)
+        outs.append((yy, gg))
+    assert outs[0][0].dtype == BF and outs[0][1].dtype == BF
+    close_bf16(outs[0][0], y, ("y", case), roundings=2 if resid is not None else 1)
+    close_bf16(outs[0][1], gx, ("gx", case))
+    assert torch.equal(outs[0][0], outs[1][0]), (case, float((outs[0][0].float() - outs[1][0].float()).abs().max()))
+    assert torch.equal(outs[0][1], outs[1][1]), (case, "input gradient")
+
+
 TINY_WGRAD_CASES = [
     # B, Cin, Cout, k, stride, pad, H, W, modulated       (<= 4 x 4 output pixels per sample: 32-pixel K-steps span whole samples)
     (300, 64, 96, 3, 1, 1, 2, 2, False), (80, 64, 64, 3, 2, 0, 9, 9, False), (257, 64, 128, 3, 1, 1, 4, 4, False),

@@ -1731,7 +1731,9 @@ def test_full_size_new_kernels_are_bitwise_the_kernels_they_replace(monkeypatch)
       (b) the same kernel without its FIR (modulated, G.layers.7.conv1's input gradient: 32 x 128 x 257 x 257 -> 256 channels);
       (c) the flat 1x1 kernel with the residual operand on Dreal.1's skip conv (96 x 64 x 128 x 128 -> 128 channels) and its chunked
           variant (32 x 256 x 64 x 64 -> 512);
-      (d) the branch-free Winograd epilogue on G.layers.7.conv2 (modulated, bias + activation)."""
+      (d) the branch-free Winograd epilogue on G.layers.7.conv2 (modulated, bias + activation);
+      (e) the flat 1x1 kernel of the bf16 family (csrc/conv_bf16_pw.hip) with the residual operand on Dreal.1's skip conv and on the
+          two-pass 128 -> 256 shape (32 x 128 x 128 x 128)."""
     import ideas_amd.op.conv as CV
     from ideas_amd.model import make_kernel
     from ideas_amd.op import conv2d, upfirdn2d
@@ -1777,6 +1779,16 @@ def test_full_size_new_kernels_are_bitwise_the_kernels_they_replace(monkeypatch)
         monkeypatch.setenv("IDEAS_B3_WINO_EPI", flag)
         outs.append(CV.conv_fwd_raw(x, w, ConvGeom(3, 3, 1, 1, False), 0.03, lin=s_, lout=d_, bias=b, act=True, act_gain=1.4))
     assert torch.equal(outs[0], outs[1])
+    del x, outs
+    # (e)
+    for (B, ci, co, R) in ((96, 64, 128, 128), (32, 128, 256, 128)):
+        x, w, r = cl(rn(B, ci, R, R)).bfloat16(), cl(rn(co, ci, 1, 1)), cl(rn(B, co, R, R)).bfloat16()
+        outs = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("IDEAS_BF16_PW", flag)
+            outs.append(CV.conv_fwd_raw(x, w, ConvGeom(1, 1, 1, 0, False), 0.1, resid=r, resid_gain=1.0))
+        assert outs[0].dtype == torch.bfloat16 and torch.equal(outs[0], outs[1]), (B, ci, co)
+        del x, r, outs
 
 
 def test_blur_conv_s2_dpp_builtin_build_is_bitwise_too():
