@@ -505,6 +505,39 @@ def test_bf16_image_kernel_reproducible_next_to_lds_heavy_kernel():
     assert bad == 0, f"{bad} of 400 launches differ"
 
 
+def test_bf16_flat_pointwise_kernel_reproducible_next_to_lds_heavy_kernel():
+    """The same regression for csrc/conv_bf16_pw.hip, whose tile loop rests on a COUNTED vmcnt wait (the tile's own stores may be in
+    flight, the DMA issued before them must have landed) and one raw barrier per tile: a few hundred launches over many tiles per
+    block, with the residual operand, while the f32 split weight gradient keeps LDS and the memory pipeline busy on another stream,
+    must all be bitwise the generic kernel's result."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom
+    torch.manual_seed(4)
+    g1, g3 = ConvGeom(1, 1, 1, 0, False), ConvGeom(3, 3, 1, 1, False)
+    x32 = torch.randn(4, 128, 256, 256, device="cuda").contiguous(memory_format=CL)
+    gy32 = torch.randn_like(x32)
+    w3 = torch.randn(128, 128, 3, 3, device="cuda").contiguous(memory_format=CL)
+    side = torch.cuda.Stream()
+    for (B, ci, co, R) in ((48, 64, 128, 128), (16, 128, 256, 128)):          # 6144 / 2048 tiles on 512 persistent blocks
+        x = torch.randn(B, ci, R, R, device="cuda").to(BF).contiguous(memory_format=CL)
+        r = torch.randn(B, co, R, R, device="cuda").to(BF).contiguous(memory_format=CL)
+        w = torch.randn(co, ci, 1, 1, device="cuda").contiguous(memory_format=CL)
+        os.environ["IDEAS_BF16_PW"] = "0"
+        try:
+            ref = CV.conv_fwd_raw(x, w, g1, 0.1, resid=r, resid_gain=0.7)
+        finally:
+            os.environ.pop("IDEAS_BF16_PW", None)
+        torch.cuda.synchronize()
+        bad = 0
+        for i in range(300):
+            if i % 4 == 0:
+                with torch.cuda.stream(side):
+                    CV.conv_wgrad_raw(gy32, x32, g3, tuple(w3.shape), 0.03)
+            bad += int(bool((CV.conv_fwd_raw(x, w, g1, 0.1, resid=r, resid_gain=0.7) != ref).any()))
+        torch.cuda.synchronize()
+        assert bad == 0, f"{bad} of 300 launches differ ({ci} -> {co})"
+
+
 # ---------------------------------------------------------------------------------- full-width backward against the oracle
 @pytest.mark.parametrize("name", ["E", "G", "Dreal", "Dco"])
 def test_full_width_gradients_bf16_vs_oracle(name, monkeypatch):
