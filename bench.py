@@ -18,6 +18,10 @@ import random
 import sys
 import time
 
+# RCCL / device-tensor sharing between the ranks of one node needs dmabuf IPC on this driver; the launcher normally exports it, a
+# bare `python -m torch.distributed.run ... bench.py` may not (read when the HIP runtime initialises, i.e. after this line)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -571,6 +575,73 @@ def cpu_baseline_config1():
     return {"value": None, "unit": "images/sec", "cores": threads, "kind": "port", "sample": "timed out"}
 
 
+def extraction_probe(trainer, args, X, device):
+    """BASELINE.json's metric names the secret-bit extraction accuracy next to images/sec: the sender / receiver block of
+    train.py:249-293 (bits -> Z -> Gstru -> G -> E -> Ex -> bits, sigma = 1, delta = 50 %) on the EMA networks as they stand after the
+    timed window, all B images on the GPU (train_step.extraction_test).  The weights are a few dozen iterations from random
+    initialisation, so ACC sits near 0.5 -- what the entry pins is that the DECISIONS are the reference arithmetic's: image 0 goes,
+    with the same EMA weights, message, jitter and texture code, through the CPU oracle in the cpu_baseline leg (finish_extraction)."""
+    import tempfile
+    from ideas_amd import train_step as TS
+    g = torch.Generator().manual_seed(4321)
+    B, s = X.shape[0], X.shape[-1] // 16
+    M = torch.randint(0, 2, (B, args.N * s * s), generator=g).float()
+    jitter = torch.rand(B, args.N * s * s, generator=g)
+    T2 = torch.rand(B, args.texture_channel, generator=g) * 2 - 1
+    hat_Z, hat_M, acc, l1 = TS.extraction_test(trainer, args, X, M, T2.to(device), False, jitter=jitter)
+    fd, path = tempfile.mkstemp(suffix=".pt", prefix="ideas_extraction_")
+    os.close(fd)
+    nets = {n: {k: v.detach().float().cpu().contiguous() for k, v in trainer[n + "_ema"].state_dict().items()} for n in ("E", "G", "Gstru", "Ex")}
+    torch.save({"nets": nets, "X": X[:1].float().cpu().contiguous(), "M": M[:1], "jitter": jitter[:1], "T2": T2[:1],
+                "cfg": dict(channel=args.channel, structure_channel=args.structure_channel, texture_channel=args.texture_channel, N=args.N,
+                            image_size=int(X.shape[-1]), channel_multiplier=args.channel_multiplier)}, path)
+    return {"bits": int(M.numel()), "acc": round(float(acc), 5), "l1": round(float(l1), 5), "sigma": 1, "delta": 0.5, "images": B,
+            "nets": "EMA copies after the timed window (random initialisation + warm-up + timed iterations: ACC ~ 0.5 by construction)",
+            "_hat_Z0": hat_Z[:1].float().cpu(), "_hat_M0": hat_M[:1].float().cpu(), "_M0": M[:1].clone(), "_file": path}
+
+
+def _oracle_extraction_worker(path: str, threads: int):
+    """Child process of the cpu_baseline leg: the CPU oracle's sender / receiver block on the dumped EMA weights (one image)."""
+    import oracle.torch_ref as O
+    torch.set_num_threads(threads)
+    d = torch.load(path, map_location="cpu", weights_only=False)
+    cfg = O.Cfg(**d["cfg"])
+    hat_Z, hat_M, acc, l1 = O.extraction_test(d["nets"], cfg, d["X"], d["M"], d["jitter"], d["T2"], False)
+    print(json.dumps({"hat_Z": hat_Z.flatten().tolist(), "hat_M": hat_M.flatten().tolist(), "acc": float(acc), "l1": float(l1)}))
+
+
+def finish_extraction(e, f32: bool):
+    """cpu_baseline leg: run the oracle child on the dump of extraction_probe and compare image 0's decisions bit for bit."""
+    import subprocess
+    if not e or "_file" not in e:
+        return e
+    path, z_gpu, m_gpu, m0 = e.pop("_file"), e.pop("_hat_Z0"), e.pop("_hat_M0"), e.pop("_M0")
+    try:
+        threads = min(os.cpu_count() or 1, 64)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--oracle-extraction-worker", path, str(threads)],
+                           capture_output=True, text=True, timeout=240, cwd=ROOT)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            e["oracle"] = "failed: " + (r.stderr or "")[-200:]
+            return e
+        d = json.loads(line[-1])
+        z_ref = torch.tensor(d["hat_Z"]).view_as(z_gpu)
+        m_ref = torch.tensor(d["hat_M"]).view_as(m_gpu)
+        flipped = int((m_ref != m_gpu).sum())
+        e["oracle_image0"] = {"bits": int(m_ref.numel()), "decisions_equal_oracle": flipped == 0, "bits_flipped": flipped,
+                              "hat_Z_rel_err": float("%.3g" % float((z_gpu - z_ref).abs().max() / z_ref.abs().max())),
+                              "acc_oracle": round(d["acc"], 5), "acc_gpu": round(float(1 - (m_gpu - m0).abs().mean()), 5),
+                              "min_abs_hat_Z": float("%.3g" % float(z_ref.abs().min())),
+                              "oracle": "oracle/torch_ref.py::extraction_test (f32, CPU, %d threads) on the same EMA weights, message, jitter, "
+                                        "texture code" % threads + ("" if f32 else "; this run is bf16 mixed precision: flipped bits are reported, not promised zero")}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return e
+
+
 def _self_launch(a) -> int:
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks here, one process per
     GPU, exactly as the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` does
@@ -595,6 +666,9 @@ def _self_launch(a) -> int:
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         _cpu_baseline_worker(*[int(v) for v in sys.argv[2:7]])
+        return
+    if len(sys.argv) >= 4 and sys.argv[1] == "--oracle-extraction-worker":
+        _oracle_extraction_worker(sys.argv[2], int(sys.argv[3]))
         return
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -623,7 +697,11 @@ def main():
             pass
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # IDEAS_DDP_FORCE_COLLECTIVE=1 (test switch, ideas_amd/ddp.py): one rank under a launcher still joins a process group and runs
+    # every collective of the multi-rank path through RCCL (mean over one rank = identity)
+    from ideas_amd.ddp import force_collective
+    forced = world == 1 and force_collective() and "MASTER_ADDR" in os.environ
+    if world > 1 or forced:
         backend = os.environ.get("IDEAS_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
@@ -640,45 +718,79 @@ def main():
 
     res = run_steps(a, a.precision, a.steps, a.warmup, device, world, rank)
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     out = step_line(a, a.precision, res, world)
+    errors = {}
+
+    def leg(name, fn):
+        """An auxiliary measurement must never cost the line its headline: failures are reported under `probe_errors`."""
+        try:
+            return fn()
+        except Exception as e:
+            errors[name] = repr(e)[:300]
+            return None
     if res.get("roofline_weighted"):
         out["roofline_weighted"] = res["roofline_weighted"]
-    out["vs_rocm_eager"] = vs_rocm_eager(out["value"], a, world)
+    if res.get("r1_reweighted"):
+        out["r1_reweighted"] = res["r1_reweighted"]
+    out["vs_rocm_eager"] = leg("vs_rocm_eager", lambda: vs_rocm_eager(out["value"], a, world))
     if a.roofline == "on":
-        out.update(rooflines(device, a.batch, a.roofline_launches, bf16))
-    if a.also_bf16 == "on" and not bf16 and world == 1:
+        out.update(leg("rooflines", lambda: rooflines(device, a.batch, a.roofline_launches, bf16, errors)) or {})
+    r2 = None
+    if a.also_bf16 == "on" and not bf16 and world == 1 and not dist.is_initialized():
         # BASELINE.json configs[4]'s single-GPU part, timed by the same process right after the f32 window: same step, same
         # synthetic batch, bf16 activations (ideas_amd/precision.py).  A short window (R1 falls on its last step or not at all is
         # stated in r1_steps_in_window); the full-length figure is `python bench.py --precision bf16`.
-        r2 = run_steps(a, "bf16", a.bf16_steps, a.bf16_warmup, device, world, rank)
-        l2 = step_line(a, "bf16", r2, world)
-        out["bf16"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "step_tflops", "step_frac_of_ceiling", "losses")}
-        out["bf16"]["r1_steps_in_window"] = l2["config"]["r1_steps_in_window"]
-        out["bf16"]["workload"] = l2["config"]["workload"]
-        if r2.get("roofline_weighted"):
-            out["bf16"]["roofline_weighted"] = r2["roofline_weighted"]
-        if a.roofline == "on":
-            out["bf16"]["roofline"] = roofline_probe_bf16(device, a.batch, a.roofline_launches)
+        def bf16_leg():
+            r2_ = run_steps(a, "bf16", a.bf16_steps, a.bf16_warmup, device, world, rank)
+            l2 = step_line(a, "bf16", r2_, world)
+            out["bf16"] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "step_tflops", "step_frac_of_ceiling", "losses")}
+            out["bf16"]["r1_steps_in_window"] = l2["config"]["r1_steps_in_window"]
+            out["bf16"]["workload"] = l2["config"]["workload"]
+            if r2_.get("roofline_weighted"):
+                out["bf16"]["roofline_weighted"] = r2_["roofline_weighted"]
+            if r2_.get("r1_reweighted"):
+                out["bf16"]["r1_reweighted"] = r2_["r1_reweighted"]
+            if a.roofline == "on":
+                out["bf16"]["roofline"] = roofline_probe_bf16(device, a.batch, a.roofline_launches)
+            return r2_
+        r2 = leg("bf16", bf16_leg)
     if a.cpu_baseline == "auto" and world == 1:
-        out["cpu_baseline"] = cpu_baseline()
-        out["cpu_baseline_config1"] = cpu_baseline_config1()
-    print(json.dumps(out))
-    if world > 1:
+        out["cpu_baseline"] = leg("cpu_baseline", cpu_baseline) or {"value": None, "unit": "images/sec", "cores": None, "kind": "port", "sample": "failed"}
+        out["cpu_baseline_config1"] = leg("cpu_baseline_config1", cpu_baseline_config1)
+        # the metric's second half ("secret-bit extraction acc"): GPU decisions against the CPU oracle on identical weights
+        out["extraction"] = leg("extraction", lambda: finish_extraction(res.get("extraction"), not bf16))
+        if r2 is not None and "bf16" in out:
+            out["bf16"]["extraction"] = leg("extraction_bf16", lambda: finish_extraction(r2.get("extraction"), False))
+    if errors:
+        out["probe_errors"] = errors
+    print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
-def rooflines(device, batch, launches, bf16):
+def rooflines(device, batch, launches, bf16, errors=None):
     probe = roofline_probe_bf16 if bf16 else roofline_probe
-    s2 = None if bf16 else roofline_probe_s2(device, batch, max(4, launches // 2))
-    return {"roofline": probe(device, batch, launches),
-            **({"roofline_s2": s2} if s2 is not None else {}),
-            "roofline_wgrad": roofline_probe_wgrad(device, batch, launches, bf16),
-            "roofline_direct": roofline_probe_direct(device, batch, launches, bf16),
-            "roofline_hbm": roofline_probe_hbm(device, batch, launches, bf16),
-            "roofline_hbm_bias_act_bwd": roofline_probe_bias_act_bwd(device, batch, launches, bf16)}
+    out = {"roofline": probe(device, batch, launches)}            # the required entry: its failure is the caller's to report
+
+    def opt(name, fn):
+        try:
+            v = fn()
+            if v is not None:
+                out[name] = v
+        except Exception as e:
+            if errors is None:
+                raise
+            errors[name] = repr(e)[:300]
+    if not bf16:
+        opt("roofline_s2", lambda: roofline_probe_s2(device, batch, max(4, launches // 2)))
+    opt("roofline_wgrad", lambda: roofline_probe_wgrad(device, batch, launches, bf16))
+    opt("roofline_direct", lambda: roofline_probe_direct(device, batch, launches, bf16))
+    opt("roofline_hbm", lambda: roofline_probe_hbm(device, batch, launches, bf16))
+    opt("roofline_hbm_bias_act_bwd", lambda: roofline_probe_bias_act_bwd(device, batch, launches, bf16))
+    return out
 
 
 def roofline_weighted(run_iteration, bf16: bool):
@@ -726,37 +838,87 @@ def run_steps(a, precision_name, steps, warmup, device, world, rank):
     gx = torch.Generator().manual_seed(1234 + rank)
     X = (torch.rand(a.batch, 3, a.image_size, a.image_size, generator=gx) * 2 - 1).to(device)
     X = X.contiguous(memory_format=torch.channels_last)
-    reducer = GradReducer() if world > 1 else None
+    dist_on = dist.is_initialized()           # world > 1, or the one-rank RCCL exercise of IDEAS_DDP_FORCE_COLLECTIVE=1
+    reducer = GradReducer() if dist_on else None
 
     def step(idx):
         return TS.train_iteration(trainer, args, X, idx, reducer=reducer)
 
     for j in range(warmup):
         step(args.d_reg_every * 1000 + j)          # first warm-up iteration exercises the R1 branch
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(1, steps + 1):
         losses = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    t_own = time.perf_counter() - t0               # this rank's own K steps (before it waits for the slowest rank)
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    ranks_seen = None
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # who took part: every rank's own time and the physical device it ran on (PCI bus id where torch exposes it -- a launcher that
+        # hands each rank ONE visible device makes every index 0 --, else the device index).  Two ranks on one device would make the
+        # "N GPUs" of the line untrue: fail loudly (IDEAS_BENCH_SHARE_GPU=1, the 1-GPU test of this code path, is the only exception).
+        props = torch.cuda.get_device_properties(device)
+        ident = [float(getattr(props, k, -1)) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        info = torch.tensor([float(rank), t_own, float(device.index)] + ident, device=device, dtype=torch.float64)
+        got = [torch.empty_like(info) for _ in range(dist.get_world_size())]
+        dist.all_gather(got, info)
+        rows = sorted([g_.tolist() for g_ in got])
+        ranks_seen = [{"rank": int(r[0]), "images_per_sec": round(a.batch * steps / r[1], 2), "ms_per_step": round(r[1] / steps * 1e3, 2),
+                       "device_index": int(r[2]), "pci": "%04x:%02x:%02x" % tuple(int(v) for v in r[3:6]) if min(r[3:6]) >= 0 else None}
+                      for r in rows]
+        keys = [(r["pci"] if r["pci"] is not None else r["device_index"]) for r in ranks_seen]
+        if len(set(keys)) != len(keys) and os.environ.get("IDEAS_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"bench.py: {len(keys)} ranks on {len(set(keys))} distinct device(s) {keys}: every rank needs its own GPU "
+                             "(LOCAL_RANK -> device index; check the launcher's device visibility)")
+    # lazy-R1 weighting of the window: K timed steps hold floor(K / 16) R1 iterations, not K / 16 (20 steps: 1 in 20).  The extra cost of
+    # an R1 iteration is measured right here (two R1 and two plain iterations, each between synchronisations) so that the line can
+    # state the rate at exactly one R1 iteration in sixteen next to the measured one.
+    r1w = None
+    if not dist_on:
+        def timed(idx):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(idx)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        base = (steps // args.d_reg_every + 2) * args.d_reg_every
+        t_r1 = min(timed(base), timed(base + args.d_reg_every))
+        t_pl = min(timed(base + 1), timed(base + 2))
+        n_r1 = sum(1 for i in range(1, steps + 1) if i % args.d_reg_every == 0)
+        extra = max(0.0, t_r1 - t_pl)
+        ms_w = ((dt - n_r1 * extra) / steps + extra / args.d_reg_every) * 1e3
+        r1w = {"r1_iteration_extra_ms": round(extra * 1e3, 2), "r1_steps_in_window": n_r1, "steps": steps,
+               "ms_per_step_at_one_r1_in_%d" % args.d_reg_every: round(ms_w, 2),
+               "images_per_sec_at_one_r1_in_%d" % args.d_reg_every: round(a.batch / (ms_w * 1e-3), 3),
+               "note": "`value` is the measured window as it is; this re-weights its R1 share to exactly 1 / d_reg_every (the FLOP model's)"}
+    extraction = None
+    if world == 1 and not dist_on and getattr(a, "cpu_baseline", "skip") == "auto":
+        try:
+            extraction = extraction_probe(trainer, args, X, device)
+        except Exception as e:                                   # never lose the line to the accuracy probe
+            extraction = {"error": repr(e)[:300]}
     weighted = None
     if getattr(a, "roofline", "off") == "on" and world == 1 and a.image_size == 256 and (a.channel, a.texture_channel) == (32, 2048):
         idx = steps + 3
         idx += 1 if idx % args.d_reg_every == 0 else 0                                   # (an iteration without the lazy-R1 branch)
-        weighted = roofline_weighted(lambda: step(idx), precision_name == "bf16")
-    res = {"dt": dt, "steps": steps, "warmup": warmup, "roofline_weighted": weighted,
+        try:
+            weighted = roofline_weighted(lambda: step(idx), precision_name == "bf16")
+        except Exception as e:
+            weighted = {"error": repr(e)[:300]}
+    res = {"dt": dt, "steps": steps, "warmup": warmup, "roofline_weighted": weighted, "r1_reweighted": r1w, "extraction": extraction,
            "n_r1": sum(1 for i in range(1, steps + 1) if i % args.d_reg_every == 0),
            "losses": {k: round(float(v.detach()), 4) for k, v in losses.items() if v.numel() == 1},
+           "ranks_seen": ranks_seen,
            "bucket_bytes": ({k: 4 * int(trainer[k].flat_g.numel()) for k in ("d_optim", "g_optim", "ex_optim") if hasattr(trainer[k], "flat_g")}
-                            if world > 1 else None)}
+                            if dist_on else None)}
     del trainer, reducer, losses, X
     import gc
     gc.collect()
@@ -787,7 +949,7 @@ def step_line(a, precision_name, res, world):
     tfl = ips / world * gflop_img / 1e3
     return {
         "metric": "train images/sec at %dx%d (G+D+Ex step)" % (a.image_size, a.image_size), "value": round(ips, 3), "unit": "images/sec",
-        "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": steps, "warmup": res["warmup"], "ms_per_step": round(dt / steps * 1e3, 2),
+        "n_gpus": (dist.get_world_size() if dist.is_initialized() else 1), "steps": steps, "warmup": res["warmup"], "ms_per_step": round(dt / steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": precision_name, "data": "synthetic",
         "config": {"workload": "IDEAS N=%d sigma=1 %dx%d batch=%d/GPU full G+D+Ex iteration (lazy R1 every 16, EMA), "
                                "%s nets, HIP kernels (BASELINE.json configs[%d]%s)"
@@ -797,10 +959,12 @@ def step_line(a, precision_name, res, world):
                                   1 if a.image_size == 128 else (4 if bf16 else (3 if a.N == 2 else 2)),
                                   "" if a.image_size >= 256 else "; Dco-less sub-step: the reference's Dco cannot run below 256x256"),
                    "global_batch": world * a.batch, "parallelism": "dp%d" % world, "r1_steps_in_window": res["n_r1"],
-                   "ranks": (dist.get_world_size() if world > 1 else 1),
-                   "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else None,
+                   "ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+                   "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist.is_initialized() else None,
+                   "collectives_forced_at_one_rank": (True if (dist.is_initialized() and world == 1) else None),
+                   "ranks_seen": res.get("ranks_seen"),
                    "grad_exchange": ("one mean all-reduce per optimiser group on its flat gradient buffer, 1/world folded into the collective; "
-                                     "D group overlapped with the G-phase generator forwards, Ex group with the G-side backward") if world > 1 else None,
+                                     "D group overlapped with the G-phase generator forwards, Ex group with the G-side backward") if dist.is_initialized() else None,
                    "allreduce_bytes_per_iteration": res["bucket_bytes"],
                    "second_backward": "literal" if a.literal_second_backward else "elided (Ex grad over Ex sub-graph)",
                    "shared_forward": "E(X), G(S1,T1) evaluated once per iteration" if not a.no_share_forward else "off",

@@ -121,6 +121,7 @@ _PROTOS = {
     "ideas_act_bwd_dot": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
 }
 EXPORTS = tuple(_PROTOS)
+ABI_VERSION = 4          # include/ideas_hip.h::IDEAS_ABI_VERSION
 
 _lib: Optional[C.CDLL] = None
 
@@ -135,11 +136,16 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C ideas_amd/csrc).  ideas_amd has no CPU / eager fallback.")
     lib = C.CDLL(LIB_PATH)
+    ver = getattr(lib, "ideas_abi_version", None)
+    if ver is None or ver() != ABI_VERSION:
+        # (checked BEFORE the symbol lookups: a stale library fails with this diagnostic, not with an AttributeError)
+        raise RuntimeError(f"libideas_hip.so ABI mismatch: the library reports version {None if ver is None else ver()}, this binding "
+                           f"needs {ABI_VERSION} (include/ideas_hip.h); rebuild with make -C ideas_amd/csrc")
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.ideas_abi_version() != 3 or lib.ideas_sizeof_conv_params() != C.sizeof(ConvParams):
+    if lib.ideas_sizeof_conv_params() != C.sizeof(ConvParams):
         raise RuntimeError("libideas_hip.so ABI mismatch (version or ideas_conv_params layout)")
     if lib.ideas_sizeof_prep_desc() != C.sizeof(PrepDesc):
         raise RuntimeError("libideas_hip.so ABI mismatch (ideas_prep_desc layout)")

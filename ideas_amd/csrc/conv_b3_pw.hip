@@ -125,9 +125,33 @@ __global__ __launch_bounds__(256, 2) void conv_b3_pw_kernel(float* __restrict__ 
             if (n < p.Cout) {
                 const float bv = bias ? bias[n] : 0.f;
                 const unsigned ybase = ((unsigned)tile * (unsigned)BM + (unsigned)(wr * MTW * 32 + 4 * lh)) * cout4 + (unsigned)n * 4u;
+                // A ragged last tile (rows past M) must not depend on how the hardware range-checks the SCALAR offset (LLVM documents
+                // soffset as excluded from the bounds check): there the whole offset goes into the lane register, where row >= M <=>
+                // offset >= y_bytes (n < Cout; no 32-bit wrap: ideas_b3_pw_ok keeps (M + 128) * Cout * 4 below 2^32) and the access is
+                // dropped / returns zero by the descriptor's bounds.  One row group at a time (sched_barrier) so that the 16 lane offsets
+                // of a group are the only ones alive.  Full tiles keep the one-register form (uniform branch).
+                const bool ragged = ((unsigned)tile + 1u) * (unsigned)BM > M;
 #pragma unroll
                 for (int a = 0; a < MTW; ++a) {
                     float rv[16];
+                    if (ragged) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            unsigned off[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) off[k] = ybase + (unsigned)(a * 32 + k + 8 * e4) * cout4;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float v = mul_rn(acc[a][4 * e4 + k], p.gain);
+                                v = mul_then_add(v, 1.0f, bv);
+                                if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                                if (resid) v = (v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)off[k], 0, 0))) * p.resid_gain;
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)off[k], 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        continue;
+                    }
                     if (resid) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_pw_kernel(float* __restrict__ 
                         if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
                         if (resid) v = (v + rv[e]) * p.resid_gain;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)ybase,
-                                                              (int)((unsigned)(a * 32 + (e & 3) + 8 * (e >> 2)) * cout4), 0);   // rows past M: dropped
+                                                              (int)((unsigned)(a * 32 + (e & 3) + 8 * (e >> 2)) * cout4), 0);
                     }
                 }
             }
@@ -304,9 +328,29 @@ __global__ __launch_bounds__(256, 2) void conv_b3_pwk_kernel(float* __restrict__
             if (np < npass && n < p.Cout) {
                 const float bv = bias ? bias[n] : 0.f;
                 const unsigned ybase = ((unsigned)tile * (unsigned)BM + (unsigned)(wr * MTW * 32 + 4 * lh)) * cout4 + (unsigned)n * 4u;
+                // (ragged last tile: row offsets in the lane register, bounds-checked -- see conv_b3_pw_kernel)
+                const bool ragged = ((unsigned)tile + 1u) * (unsigned)BM > M;
 #pragma unroll
                 for (int a = 0; a < MTW; ++a) {
                     float rv[16];
+                    if (ragged) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            unsigned off[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) off[k] = ybase + (unsigned)(a * 32 + k + 8 * e4) * cout4;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float v = mul_rn(acc[np][a][4 * e4 + k], p.gain);
+                                v = mul_then_add(v, 1.0f, bv);
+                                if (p.act) v = (v > 0.f ? v : v * p.alpha) * p.act_gain;
+                                if (resid) v = (v + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, (int)off[k], 0, 0))) * p.resid_gain;
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)off[k], 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        continue;
+                    }
                     if (resid) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
@@ -480,8 +524,9 @@ int ideas_b3_pw_ok(const ideas_conv_params* p, const float* in_scale, const floa
     // tile shares the staged pixels between more MFMAs), so those stay where they were.
     if (p->Cin > 128 && (p->Cin % 128 || p->Cin > 1024 || !resid)) return 0;
     const int64_t M = (int64_t)p->B * p->OH * p->OW;
-    // (+ one tile of slack on the x offsets: the prefetch of the last, partial tile computes offsets past M rows)
-    return (M + 128) * p->Cin * 4 < 0xffffffffLL && M * p->Cout * 4 < 0xffffffffLL && (int64_t)p->Cin * p->Cout * 6 < 0xffffffffLL;
+    // (+ one tile of slack on the x AND y offsets: the prefetch and the epilogue of the last, partial tile compute offsets past M rows,
+    // which must not wrap around 2^32 into the start of the tensor)
+    return (M + 128) * p->Cin * 4 < 0xffffffffLL && (M + 128) * p->Cout * 4 < 0xffffffffLL && (int64_t)p->Cin * p->Cout * 6 < 0xffffffffLL;
 }
 
 int ideas_b3_pw_fwd(void* y, const void* x, const void* wplanes, const float* bias, const void* resid, const ideas_conv_params* p,

@@ -69,6 +69,15 @@ class Pending:
             self.post_scale = 1.0
 
 
+def force_collective() -> bool:
+    """TEST switch (IDEAS_DDP_FORCE_COLLECTIVE=1, read per call): issue the collectives even when the group has ONE rank.  The mean
+    over one rank is the identity, so results do not change -- but ReduceOp.AVG on RCCL, the async work handle, its wait() on the
+    current stream, the deferred optimiser steps of train_iteration and the start-up broadcast then run through ProcessGroupNCCL on
+    a 1-GPU box exactly as they will on eight (tests/test_bench_multirank_gpu.py).  Never set in production."""
+    import os
+    return os.environ.get("IDEAS_DDP_FORCE_COLLECTIVE", "0") == "1"
+
+
 def _has_avg(group=None) -> bool:
     return dist.get_backend(group) == "nccl"          # RCCL implements ncclAvg; gloo / mpi do not
 
@@ -77,7 +86,7 @@ def all_reduce_mean_(flat: torch.Tensor, group=None, async_op: bool = False):
     """In-place mean of ``flat`` over the ranks of ``group``: ONE collective, the 1/world folded into it where the
     backend can (no separate division pass over the bucket)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force_collective():
         return Pending() if async_op else None
     if _has_avg(group):
         pend = Pending(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group, async_op=True), flat)
@@ -180,7 +189,7 @@ def broadcast_parameters(modules: Sequence[torch.nn.Module], src: int = 0, group
     second moments — a resumed rank 0 must hand those over too): each is ONE broadcast of a contiguous buffer.
     Parameters not covered by a flat buffer are sent one by one through a 1-D view of their dense storage (a
     contiguous temporary + copy back for the rare non-dense one)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective()):
         return
     covered = set()
     for opt in optimizers:

@@ -217,11 +217,16 @@ class styles_for:
                 or any(c.modulation.activation or c.modulation.weight.shape[1] != style.shape[-1] for c in self.convs)):
             return self
         w0 = self.convs[0].modulation.weight
+        # (the tuple depends on EVERY layer's modulation weight and bias: an optimiser that steps some of them but not layer 0
+        # must still drop it -- conv_plan.cached_on(deps=...))
+        deps = [t for c in self.convs[1:] for t in (c.modulation.weight, c.modulation.bias) if t is not None]
+        if self.convs[0].modulation.bias is not None:
+            deps.append(self.convs[0].modulation.bias)
         if torch.is_grad_enabled():
-            tup = conv_plan.cached_on(w0, ("styles", 1), style, self._make)
+            tup = conv_plan.cached_on(w0, ("styles", 1), style, self._make, deps=deps)
         else:
             hit = conv_plan.peek_on(w0, ("styles", 1), style)
-            tup = tuple(t.detach() for t in hit) if hit is not None else conv_plan.cached_on(w0, ("styles", 0), style, self._make)
+            tup = tuple(t.detach() for t in hit) if hit is not None else conv_plan.cached_on(w0, ("styles", 0), style, self._make, deps=deps)
         for c, s in zip(self.convs, tup):
             c.__dict__["_pre_style"] = (style, s)
         self.set = True

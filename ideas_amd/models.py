@@ -257,7 +257,7 @@ class ResBlock(nn.Module):
         from .op import conv as _cv
         from .precision import activation_dtype
         c1, a1, refl, blur, c2, a2 = self._fused
-        key = (tuple(x.shape), x.dtype, torch.is_grad_enabled(), c2.weight.requires_grad, activation_dtype(), _cv.BLUR_CONV,
+        key = (tuple(x.shape), x.dtype, str(x.device), torch.is_grad_enabled(), c2.weight.requires_grad, activation_dtype(), _cv.BLUR_CONV,
                _cv.BLUR_CONV_MIN_BLOCKS, _cv.BLUR_CONV_MIN_OW, _cv.MATH)
         memo = self.__dict__.setdefault("_pair_ok_memo", {})
         hit = memo.get(key)

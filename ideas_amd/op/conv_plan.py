@@ -200,6 +200,7 @@ def cache_clear(params=None, refill: bool = True) -> None:
         return
     if params is None:
         _CACHE.clear()
+        _DEPS.clear()
         if refill:
             _prefill(None)
         return
@@ -212,10 +213,15 @@ def cache_clear(params=None, refill: bool = True) -> None:
             merged.append([a, b])
     import bisect
     starts = [m[0] for m in merged]
+    def stepped(addr):
+        i = bisect.bisect_right(starts, addr) - 1
+        return i >= 0 and addr < merged[i][1]
     for k in [k for k in _CACHE]:
-        i = bisect.bisect_right(starts, k[0]) - 1
-        if i >= 0 and k[0] < merged[i][1]:
+        # an entry derived from SEVERAL parameters (model.styles_for: all sixteen modulation layers under the first one's key) lists
+        # the others in _DEPS: stepping any of them drops it
+        if stepped(k[0]) or any(stepped(a) for a in _DEPS.get(k, ())):
             del _CACHE[k]
+            _DEPS.pop(k, None)
     if refill:
         _prefill(merged)
 
@@ -278,12 +284,16 @@ def _budget_admit(k, nbytes: int) -> bool:
     return True
 
 
-def cached_on(w: torch.Tensor, key, t: torch.Tensor, make, budget: bool = False):
+_DEPS = {}          # cache key -> addresses of further parameters the entry was derived from (cached_on(..., deps=...))
+
+
+def cached_on(w: torch.Tensor, key, t: torch.Tensor, make, budget: bool = False, deps=()):
     """`make()` memoised on a parameter (as ``cached``) AND on the identity of a second tensor `t` (address + version counter) --
     the per-sample styles of a modulated conv: G is applied to the same texture code two or three times per iteration (train.py:58,
     :68, :145-160), and everything derived from (weights, styles) -- the styles themselves, the demodulation factors, the bf16
     per-sample weight packs -- is then the same.  The entry keeps `t` alive, so its address cannot be reused by another tensor
-    while the entry exists.  IDEAS_STYLE_CACHE=0 switches it off (A/B)."""
+    while the entry exists.  ``deps``: further parameters the value depends on (cache_clear drops the entry when any of them is
+    stepped, not only `w`).  IDEAS_STYLE_CACHE=0 switches it off (A/B)."""
     if _CACHE is None or not STYLE_CACHE:
         return make()
     base = w._base if w._base is not None else w
@@ -296,6 +306,8 @@ def cached_on(w: torch.Tensor, key, t: torch.Tensor, make, budget: bool = False)
         if budget and torch.is_tensor(v[1]) and not _budget_admit(k, v[1].numel() * v[1].element_size()):
             return v[1]                      # over budget: used once by the caller, not kept
         _CACHE[k] = v
+        if deps:
+            _DEPS[k] = tuple(d.data_ptr() for d in deps)
     elif budget:
         BUDGET_STATS["hit"] += 1
     return v[1]

@@ -161,7 +161,7 @@ def train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Option
     finally:
         # an exception between a deferred exchange's start and its finish() must not leave the all-reduce un-waited while the next
         # iteration's zero_grad writes the same flat buffer
-        for d in pending:
+        for d in list(pending):          # (abandon() removes itself from the list: iterate over a copy)
             d.abandon()
         scratch.end()
         conv_plan.cache_end()
@@ -204,7 +204,7 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         try:
             return _train_iteration(trainer, args, X, iter_idx, draws, reducer, hook, own)
         finally:
-            for d in own:
+            for d in list(own):
                 d.abandon()
     if draws is None:
         draws = draw_step(args, X.shape[0], X.shape[-1], X.device)

@@ -35,8 +35,13 @@
 extern "C" {
 #endif
 
-#define IDEAS_ABI_VERSION 3   /* 2: the per-sample reductions of the modulated-conv backward accumulate in double (round 3);
-                                 3: ideas_demod_bwd overwrites dot_d, ideas_weight_prep_batched added */
+#define IDEAS_ABI_VERSION 4   /* 2: the per-sample reductions of the modulated-conv backward accumulate in double (round 3);
+                                 3: ideas_demod_bwd overwrites dot_d, ideas_weight_prep_batched added;
+                                 4: the entry points added since 3 are REQUIRED by the Python binding -- ideas_patch_resize,
+                                    ideas_image_u8_to_f32, ideas_stream_create, ideas_linear_fwd / _bwd_x / _bwd_w +
+                                    ideas_sizeof_linear_seg (minimum version for the EqualLinear API), and what round 6 adds
+                                    (see the end of this header).  A binding checks `ideas_abi_version() >= 4` before it looks
+                                    any of them up. */
 
 enum { IDEAS_NCHW = 0, IDEAS_NHWC = 1 };
 /* `dtype` of the convolution entry points.  Tensors are f32 in HBM for both values.

@@ -1,0 +1,137 @@
+"""Worker of tests/test_ddp_gpu.py::test_one_rank_through_rccl_*: the multi-rank branch of the product path on RCCL itself.
+
+A 1-GPU box cannot give RCCL a second rank (it refuses two ranks on one device), and gloo's device all-reduce blocks the host, so the
+2-rank gloo tests never run the stream choreography the 8-GPU bench will: all-reduce launched ASYNC on ProcessGroupNCCL's own stream
+behind an event of the launching stream, ``work.wait()`` ordering the current stream behind it, the D group's exchange in flight
+under the generator forwards of the G phase, the Ex group's under the G-side backward, the deferred optimiser steps, and the
+grad_sink side stream whose atomics write straight into the all-reduce bucket.  IDEAS_DDP_FORCE_COLLECTIVE=1 makes
+``ddp.all_reduce_mean_`` / ``broadcast_parameters`` issue their collectives at world size 1 (mean over one rank = identity), so the
+whole of train_iteration runs through ProcessGroupNCCL here exactly as it will there (stands for stylegan2/train.py:372-373,426-438).
+
+Checks: (1) 7 mean all-reduces were issued in two iterations (d, ex, g; d, r1, ex, g in launch order) on ReduceOp.AVG, on the fused optimisers' flat
+gradient buffers (no private bucket); (2) gradients at every optimiser step and the final parameters equal those of the same two
+iterations WITHOUT a reducer up to the atomics' summation order (the weight-gradient kernels add with f32 atomics, so two runs of the
+same iteration are not bitwise equal either: the bound is the one of two reducer-less runs, measured in the same process);
+(3) repeated three times next to an LDS-heavy kernel on another stream, the reducer run reproduces itself within that same bound."""
+import os
+import random
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    assert os.environ.get("IDEAS_DDP_FORCE_COLLECTIVE") == "1"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+    assert dist.get_world_size() == 1
+    from ideas_amd import ddp, precision, train_step as TS
+    from ideas_amd.ddp import GradReducer, broadcast_parameters
+    from ideas_amd.models import init_model
+    from ideas_amd.op import conv as CV
+    from ideas_amd.optim import fuse_optimizers
+    bf16 = os.environ.get("IDEAS_TEST_PRECISION", "f32") == "bf16"
+    precision.set_activation_dtype("bf16" if bf16 else "f32")
+    # 256x256 so that the real co-occurrence discriminator takes part (models.py:400 needs 64x64 patches); narrow networks
+    args = TS.default_args(channel=8, texture_channel=128, channel_multiplier=0.25, image_size=256, batch_size=2, d_reg_every=2, num_iters=10)
+
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def spy(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        calls.append((str(op), int(t.numel()), bool(async_op), int(t.data_ptr())))
+        return real_all_reduce(t, op=op, group=group, async_op=async_op)
+    dist.all_reduce = spy
+
+    def fresh():
+        torch.manual_seed(3)
+        tr = TS.build_trainer(args, "cpu", init_model)
+        for v in tr.values():
+            if isinstance(v, torch.nn.Module):
+                v.cuda()
+        fuse_optimizers(tr, args)
+        return tr
+
+    B = 2
+    gen = torch.Generator().manual_seed(100)
+    X = (torch.rand(B, 3, 256, 256, generator=gen) * 2 - 1).cuda().contiguous(memory_format=torch.channels_last)
+    Zs = (torch.rand(4, B, 1, 16, 16, generator=gen) * 2 - 1).cuda()
+    Ts = (torch.rand(4, B, 128, generator=gen) * 2 - 1).cuda()
+    random.seed(9)
+    torch.manual_seed(9)
+    boxes = [[TS.draw_boxes(256, 256, n) for n in (8, 8, 32, 8, 32)] for _ in range(2)]
+
+    def draws(it):
+        b = boxes[it]
+        return TS.StepDraws(Z_d=Zs[2 * it], T2_d=Ts[2 * it], boxes_d_fake=b[0], boxes_d_real=b[1], boxes_d_ref=b[2],
+                            Z_g=Zs[2 * it + 1], T2_g=Ts[2 * it + 1], boxes_g_fake=b[3], boxes_g_ref=b[4])
+
+    # a stream of LDS-heavy, HBM-heavy work beside the iteration (the neighbour of test_..._next_to_lds_heavy_kernel): a mis-ordered
+    # wait shows up far more readily when the collective's stream and the side stream are not alone on the device
+    noise_stream = torch.cuda.Stream()
+    na = torch.randn(4096, 4096, device="cuda")
+
+    def run(with_reducer: bool, noisy: bool = False):
+        tr = fresh()
+        if with_reducer:
+            broadcast_parameters([v for v in tr.values() if isinstance(v, torch.nn.Module)],
+                                 optimizers=[tr[k] for k in ("d_optim", "g_optim", "ex_optim")])
+        reducer = GradReducer() if with_reducer else None
+        log = []
+
+        def hook(tag, ps):
+            log.append((tag, torch.cat([p.grad.detach().flatten().float() for p in ps]).clone()))
+        for it in range(2):
+            if noisy:
+                with torch.cuda.stream(noise_stream):
+                    for _ in range(40):
+                        torch.mm(na, na)
+            TS.train_iteration(tr, args, X, it + 1, draws=draws(it), reducer=reducer, hook=hook)
+        torch.cuda.synchronize()
+        if with_reducer:
+            assert not reducer.buckets, "GradReducer built its own bucket instead of adopting the fused optimiser's flat gradient buffer"
+            assert CV._SINK["stream"] is not None
+        flat = torch.cat([tr[k].flat_p.detach().clone() for k in ("d_optim", "g_optim", "ex_optim")])
+        return log, flat, {k: tr[k].flat_g.data_ptr() for k in ("d_optim", "g_optim", "ex_optim")}
+
+    def dist_of(a, b):
+        """(worst relative gradient difference over the optimiser steps, fraction of parameters that differ by more than 1e-6)"""
+        (la, fa, _), (lb, fb, _) = a, b
+        assert [t for t, _ in la] == [t for t, _ in lb] == ["d", "g", "ex", "d", "r1", "g", "ex"], [t for t, _ in la]
+        worst = max(float((x - y).abs().max() / y.abs().max().clamp_min(1e-30)) for (_, x), (_, y) in zip(la, lb))
+        return worst, float(((fa - fb).abs() > 1e-6).float().mean())
+
+    base1, base2 = run(False), run(False)
+    n0 = len(calls)
+    assert n0 == 0, "a reducer-less run must not touch the process group"
+    noise_g, noise_p = dist_of(base1, base2)           # what the atomics' order alone does to two identical runs
+    red = run(True)
+    # (1) the collectives were issued: 3 broadcasts are not all_reduce; 7 mean all-reduces, async, AVG, on the flat gradient buffers
+    ar = calls[n0:]
+    assert len(ar) == 7, ar
+    assert all("AVG" in op.upper() and a for op, _, a, _ in ar), ar
+    assert {p for _, _, _, p in ar} == set(red[2].values()), "all-reduce ran on something else than the optimisers' flat gradient buffers"
+    # (2) same numbers as without a reducer, up to the run-to-run noise of the atomics (x4 margin, floors for an exactly reproducible pair)
+    g_err, p_frac = dist_of(red, base1)
+    assert g_err <= max(4 * noise_g, 1e-4 if not bf16 else 2e-3), (g_err, noise_g)
+    assert p_frac <= max(4 * noise_p, 2e-3), (p_frac, noise_p)
+    # (3) reproducible next to other work, three times
+    for _ in range(3):
+        again = run(True, noisy=True)
+        ge, pf = dist_of(again, base1)
+        assert ge <= max(4 * noise_g, 1e-4 if not bf16 else 2e-3) and pf <= max(4 * noise_p, 2e-3), (ge, pf, noise_g, noise_p)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("one-rank RCCL ok: 7 all-reduces per two iterations; gradient diff vs reducer-less run %.2e (run-to-run %.2e), parameters differing %.2e (%.2e)"
+          % (g_err, noise_g, p_frac, noise_p), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("IDEAS_GOLDEN_OUT", HERE)      # where fixtures are written (tests regenerate into a scratch directory)
 REF = os.environ.get("IDEAS_REFERENCE", "/root/reference")
 
 
@@ -469,6 +470,7 @@ def run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco):
     torch.Tensor.cuda = lambda self, *a, **k: self
     import train as T
     tmp = tempfile.mkdtemp()
+    run_reference_train.last_dir = tmp          # gen_ckpt reads the checkpoints the reference wrote there
     cwd = os.getcwd()
     os.chdir(tmp)
     os.makedirs("exp/samples"); os.makedirs("exp/checkpoints")
@@ -573,7 +575,7 @@ def run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco):
     return trainer, draws, log, losses_per_iter, test_lines
 
 
-def gen_step(RM, RU, RL, RO, which):
+def gen_step(RM, RU, RL, RO, which, save_every=10 ** 9, file_name=None, extra=None):
     N = 1
     if which == "r64":
         R, B, n_iters, zero_dco = 64, 2, 2, True
@@ -602,8 +604,8 @@ def gen_step(RM, RU, RL, RO, which):
         args = tiny_args(R, N=N)
     args.__dict__.update(num_iters=n_iters, start_iter=0, lambda_Ex=10.0, lr=0.002, batch_size=B, real_r1=10.0,
                          texture_r1=1.0, dist_r1=1.0, ref_crop=4, n_crop=8, d_reg_every=d_reg_every,
-                         log_every=1, show_every=n_iters, save_every=10 ** 9)
-    seed = {"r64": 77, "r64_N2": 79, "r128": 80, "r256_N2": 81, "r256_full": 82}.get(which, 78)
+                         log_every=1, show_every=n_iters, save_every=save_every)
+    seed = {"r64": 77, "r64_N2": 79, "r128": 80, "r256_N2": 81, "r256_full": 82, "ckpt": 83}.get(which, 78)
     gx = torch.Generator().manual_seed(seed + 100)
     X = torch.rand(B, 3, R, R, generator=gx) * 2 - 1
     trainer, draws, log, losses, test_lines = run_reference_train(RM, RU, args, X, n_iters, seed, zero_dco)
@@ -639,10 +641,105 @@ def gen_step(RM, RU, RL, RO, which):
         ps = list(trainer[n_].parameters())
         cks[n_] = [float(sum(p.double().sum() for p in ps)), float(sum(p.double().abs().sum() for p in ps))]
     out["final_checksums"] = np.array(json.dumps(cks))
-    np.savez_compressed(os.path.join(HERE, f"step_{which}.npz"), **out)
-    print(f"step_{which}.npz", len(out), "arrays;", test_lines)
+    if extra is not None:
+        extra(out, args, trainer)
+    file_name = file_name or f"step_{which}.npz"
+    np.savez_compressed(os.path.join(OUT, file_name), **out)
+    print(file_name, len(out), "arrays;", test_lines)
     for ld in losses:
         print(ld)
+
+
+def gen_ckpt(RM, RU, RL, RO):
+    """A checkpoint WRITTEN BY the reference (train.py:308-322), as data.  The unmodified train() runs two iterations at 256x256
+    (tiny width, real Dco, batch 1, d_reg_every = 2 so that iteration 2 takes the lazy-R1 branch) with save_every = 1; the file it
+    saves after iteration 1 -- {'iter_idx', 'N', 'trainer': {11 networks + 3 optimisers}, 'args'} -- is read back here and stored as
+    arrays: every state-dict tensor in the reference's key order, every Adam state entry (step / exp_avg / exp_avg_sq per parameter
+    index), the param_groups and the args as JSON.  No pickle is committed.  Beside it: the usual step-fixture record of BOTH
+    iterations (draws, losses, gradient norms and direction sketches at every optimiser step, final checksums), so that a trainer
+    resumed from this checkpoint can replay iteration 2 against the reference's own iteration 2."""
+    def extra(out, args, trainer):
+        path = os.path.join(run_reference_train.last_dir, "exp", "checkpoints", "1.pt")
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        assert ck["iter_idx"] == 1 and set(ck.keys()) == {"iter_idx", "N", "trainer", "args"}
+        out["ck.iter_idx"], out["ck.N"] = np.array(ck["iter_idx"]), np.array(ck["N"])
+        a = {k: (f"1/{v.den}" if isinstance(v, Shrink) else (list(v) if isinstance(v, tuple) else v)) for k, v in vars(ck["args"]).items()}
+        out["ck.args"] = np.array(json.dumps(a))
+        out["ck.trainer_keys"] = np.array(json.dumps(list(ck["trainer"].keys())))
+        sums = {}
+        # The reference's ImageLevelDiscriminator cannot be narrowed (models.py:336-341 hard-codes 512 channels below 64x64): 24 M
+        # parameters = 96 MB of weights + 192 MB of Adam state in this checkpoint.  Its tensors above BIG elements (and the Adam state
+        # of those parameters) are therefore NOT stored; what is stored for each of them is its shape, its f64 sum / abs-sum and 8
+        # seeded +-1 projections (`sketch`).  tests/test_host_logic.py loads the COMPLETE file, regenerated by this script, when
+        # /root/reference is present; the GPU test fills the omitted tensors from its own iteration 1 and checks them against these.
+        BIG = 1 << 16
+        dreal_names = [n_ for n_, _ in trainer["Dreal"].named_parameters()]
+        omitted = []
+        for name, sd in ck["trainer"].items():
+            if name.endswith("_optim"):
+                out[f"ck.{name}.param_groups"] = np.array(json.dumps(sd["param_groups"]))
+                out[f"ck.{name}.state_keys"] = np.array(json.dumps([[int(i), list(st.keys())] for i, st in sd["state"].items()]))
+                for i, st in sd["state"].items():
+                    for k, v in st.items():
+                        if name == "d_optim" and torch.is_tensor(v) and v.numel() > BIG and int(i) < len(dreal_names):
+                            omitted.append([f"ck.{name}.state.{i}.{k}", list(v.shape), float(v.double().sum()), float(v.double().abs().sum()),
+                                            sketch(v, 7000 + int(i))])
+                            continue
+                        out[f"ck.{name}.state.{i}.{k}"] = npy(v) if torch.is_tensor(v) else np.array(v)
+            else:
+                out[f"ck.{name}.keys"] = np.array(json.dumps(list(sd.keys())))
+                for j, (k, v) in enumerate(sd.items()):
+                    if name == "Dreal" and v.numel() > BIG:
+                        omitted.append([f"ck.{name}/{k}", list(v.shape), float(v.double().sum()), float(v.double().abs().sum()), sketch(v, 8000 + j)])
+                        continue
+                    out[f"ck.{name}/{k}"] = npy(v)
+                fl = [v.double() for k, v in sd.items() if v.is_floating_point()]
+                sums[name] = [float(sum(v.sum() for v in fl)), float(sum(v.abs().sum() for v in fl))]
+        out["ck.omitted"] = np.array(json.dumps(omitted))
+        out["ck.dreal_param_names"] = np.array(json.dumps(dreal_names))
+        full = os.environ.get("IDEAS_CKPT_COPY")          # tests/test_host_logic.py: keep the reference's own file for the complete check
+        if full:
+            import shutil
+            shutil.copy(path, full)
+        out["ck.checksums"] = np.array(json.dumps(sums))
+        print("checkpoint 1.pt:", {k: len(v) if hasattr(v, "__len__") else v for k, v in ck["trainer"].items()})
+    gen_step(RM, RU, RL, RO, "ckpt", save_every=1, file_name="ckpt_r256.npz", extra=extra)
+
+
+def gen_ops6(RM, RU, RL, RO):
+    """Round-6 additions to the op vectors (kept in their own file so that ops.npz regenerates bit-identically):
+    ScaledLeakyReLU (stylegan2/model.py:169-178) forward / gradient / gradient of the gradient, and the only way the layer library
+    reaches it, ConvLayer(bias=False, activate=True) (models.py:125-131) -- no IDEAS network instantiates it."""
+    out = {}
+    g = torch.Generator().manual_seed(6)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    m = RL.ScaledLeakyReLU(0.2)
+    for tag, shape in (("slr4", (2, 5, 7, 6)), ("slr2", (3, 9))):
+        x = rn(*shape).requires_grad_(True)
+        y = m(x)
+        gy = rn(*shape).requires_grad_(True)
+        (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+        ggx = rn(*shape)
+        (ggy,) = torch.autograd.grad((gx * ggx).sum(), gy)
+        out.update({f"{tag}.x": npy(x), f"{tag}.y": npy(y), f"{tag}.gy": npy(gy), f"{tag}.gx": npy(gx), f"{tag}.ggx": npy(ggx), f"{tag}.ggy": npy(ggy)})
+    for tag, kw, hw in (("cl_slr", dict(), (9, 8)), ("cl_slr_down", dict(downsample=True), (10, 10)), ("cl_slr_reflect", dict(padding="reflect"), (7, 9))):
+        layer = RM.ConvLayer(4, 6, 3, bias=False, activate=True, **kw)
+        assert isinstance(layer[-1], RL.ScaledLeakyReLU)
+        with torch.no_grad():
+            for p_ in layer.parameters():
+                p_.copy_(rn(*p_.shape))
+        x = rn(2, 4, *hw).requires_grad_(True)
+        y = layer(x)
+        gy = rn(*y.shape)
+        grads = torch.autograd.grad(y, [x] + list(layer.parameters()), gy)
+        out[f"{tag}.keys"] = np.array(json.dumps(list(layer.state_dict().keys())))
+        for k, v in layer.state_dict().items():
+            out[f"{tag}.sd/{k}"] = npy(v)
+        out.update({f"{tag}.x": npy(x), f"{tag}.y": npy(y), f"{tag}.gy": npy(gy), f"{tag}.gx": npy(grads[0])})
+        for (n_, _), q in zip(layer.named_parameters(), grads[1:]):
+            out[f"{tag}.g/{n_}"] = npy(q)
+    np.savez_compressed(os.path.join(HERE, "ops_r06.npz"), **out)
+    print("ops_r06.npz", len(out), "arrays")
 
 
 if __name__ == "__main__":
@@ -669,3 +766,7 @@ if __name__ == "__main__":
         gen_step(*mods, "r256_full")
     if "pathlen" in todo:
         gen_pathlen(*mods)
+    if "ops6" in todo:                  # round 6 (own files: the fixtures above regenerate bit-identically)
+        gen_ops6(*mods)
+    if "ckpt" in todo:
+        gen_ckpt(*mods)

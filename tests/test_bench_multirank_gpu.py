@@ -40,6 +40,36 @@ def test_bench_spawns_its_own_ranks(extra):
     assert d["value"] > 0 and all(v == v for v in d["losses"].values())
 
 
+@pytest.mark.parametrize("extra", [[], ["--precision", "bf16"]])
+def test_bench_under_an_external_launcher_through_rccl(extra):
+    """The driver's own launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`) with N = 1 and IDEAS_DDP_FORCE_COLLECTIVE=1: bench.py joins a process group on backend "nccl" (RCCL),
+    builds the GradReducer, and every gradient exchange of its iterations (the warm-up's first one takes the R1 branch) is a real
+    ReduceOp.AVG all-reduce on RCCL's stream; the line names the backend, the ranks it saw with their devices and per-rank rates.
+    HSA_ENABLE_IPC_MODE_LEGACY is deliberately NOT in the environment: bench.py must set it itself."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, IDEAS_DDP_FORCE_COLLECTIVE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY", "IDEAS_BENCH_SHARE_GPU", "IDEAS_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "2", "--channel", "8",
+           "--texture-channel", "128", "--roofline", "off", "--also-bf16", "off", "--cpu-baseline", "skip"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["ranks"] == 1 and c["dist_backend"] == "nccl (RCCL)" and c["collectives_forced_at_one_rank"] is True
+    assert len(c["ranks_seen"]) == 1 and c["ranks_seen"][0]["rank"] == 0 and c["ranks_seen"][0]["images_per_sec"] > 0
+    assert set(c["allreduce_bytes_per_iteration"]) == {"d_optim", "g_optim", "ex_optim"}
+    assert d["value"] > 0 and all(v == v and abs(v) < 1e4 for v in d["losses"].values())
+
+
 def test_bench_refuses_more_ranks_than_devices():
     import torch
     n = torch.cuda.device_count() + 1

@@ -1319,6 +1319,53 @@ def test_grad_sink_modulated_conv_and_linear(ops):
         assert rel_err(p.grad, 2 * g) < 3e-5, (tuple(p.shape), rel_err(p.grad, 2 * g))
 
 
+# --------------------------------------------------------------------------------------------- ScaledLeakyReLU
+@pytest.mark.parametrize("tag", ["slr4", "slr2"])
+@pytest.mark.parametrize("cl", [False, True])
+def test_scaled_leaky_relu_golden(tag, cl):
+    """ideas_amd.model.ScaledLeakyReLU (stylegan2/model.py:169-178: leaky_relu(x, 0.2) * sqrt(2), no bias) on the reference's own
+    vectors (tests/golden/ops_r06.npz): forward BIT-exact (select, multiply -- the op order of fused_bias_act_kernel.cu:26-47 without
+    the add), gradient and gradient of the gradient bit-exact too (elementwise masks)."""
+    from conftest import Golden
+    from ideas_amd.model import ScaledLeakyReLU
+    g = Golden("ops_r06.npz")
+    m = ScaledLeakyReLU(0.2)
+    x = dev(g.t(f"{tag}.x"), cl).requires_grad_(True)
+    y = m(x)
+    assert torch.equal(y.cpu(), g.t(f"{tag}.y"))
+    gy = dev(g.t(f"{tag}.gy"), cl).requires_grad_(True)
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    assert torch.equal(gx.cpu(), g.t(f"{tag}.gx"))
+    (ggy,) = torch.autograd.grad((gx * dev(g.t(f"{tag}.ggx"), cl)).sum(), gy)
+    assert torch.equal(ggy.cpu(), g.t(f"{tag}.ggy"))
+    with torch.no_grad():                              # and against the oracle's expression on fresh data, both layouts
+        z = torch.randn(3, 6, 5, 4)
+        assert torch.equal(m(dev(z, cl)).cpu(), F.leaky_relu(z, 0.2) * O.SQRT2)
+
+
+@pytest.mark.parametrize("tag,kw", [("cl_slr", {}), ("cl_slr_down", {"downsample": True}), ("cl_slr_reflect", {"padding": "reflect"})])
+def test_conv_layer_with_scaled_leaky_relu_golden(tag, kw):
+    """ConvLayer(bias=False, activate=True) (models.py:125-131) -> EqualConv2d without bias + ScaledLeakyReLU: the reference's module,
+    state-dict keys included, on its own vectors; same-resolution, downsampling (Blur -> stride 2) and mirror-padded forms."""
+    from conftest import Golden
+    from ideas_amd.model import ScaledLeakyReLU
+    from ideas_amd.models import ConvLayer
+    g = Golden("ops_r06.npz")
+    layer = ConvLayer(4, 6, 3, bias=False, activate=True, **kw)
+    assert isinstance(layer[-1], ScaledLeakyReLU)
+    assert list(layer.state_dict().keys()) == g.json(f"{tag}.keys")
+    layer.load_state_dict({k: g.t(f"{tag}.sd/{k}") for k in g.json(f"{tag}.keys")}, strict=True)
+    layer.cuda()
+    x = dev(g.t(f"{tag}.x"), True).requires_grad_(True)
+    y = layer(x)
+    assert rel_err(y, g.t(f"{tag}.y")) < TOL
+    params = list(layer.named_parameters())
+    grads = torch.autograd.grad(y, [x] + [p for _, p in params], dev(g.t(f"{tag}.gy"), True))
+    assert rel_err(grads[0], g.t(f"{tag}.gx")) < GTOL
+    for (n_, _), q in zip(params, grads[1:]):
+        assert rel_err(q, g.t(f"{tag}.g/{n_}")) < GTOL, n_
+
+
 # --------------------------------------------------------------------------------------------- 1x1 layers as a flat GEMM
 @pytest.mark.parametrize("case", [(2, 64, 128, 16, 16, "plain"), (3, 32, 64, 9, 14, "resid"), (1, 128, 256, 24, 8, "plain"), (2, 16, 48, 7, 5, "ba"),
                                   (1, 96, 136, 10, 13, "resid"), (5, 128, 64, 8, 8, "ba"), (2, 112, 320, 6, 6, "plain"), (1, 80, 32, 33, 3, "resid"),
@@ -1359,6 +1406,36 @@ def test_pointwise_flat_gemm_kernel_is_bitwise_the_generic_kernel(case, monkeypa
     if outs[0][1] is not None:
         assert rel_err(outs[0][1], gx) < GTOL
         assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("case", [(1, 64, 128, 4, 4, False), (1, 32, 64, 3, 7, True), (1, 128, 48, 9, 8, False), (2, 16, 136, 5, 5, True),
+                                  (1, 96, 32, 1, 17, False), (3, 64, 64, 11, 13, True), (1, 256, 128, 5, 5, True), (1, 512, 320, 3, 3, True),
+                                  (1, 128, 256, 1, 1, False)])
+def test_pointwise_flat_gemm_kernel_never_writes_past_its_output(case):
+    """the rows past M of a ragged last tile are dropped by the buffer descriptor's bounds check.  The output lives
+    INSIDE a larger buffer filled with a bit pattern; after the launch every byte behind the M * Cout outputs (and in front of them)
+    must still hold it -- M from 1 to 429 rows, i.e. tiles whose in-range part is a few rows of 64 / 128, both kernels (Cin <= 128 and
+    the K-chunked one), with and without the residual operand (whose loads take the same offsets)."""
+    import ideas_amd.op.conv as CV
+    from ideas_amd.op.conv_plan import ConvGeom, plan_fwd
+    B, ci, co, H, W, with_resid = case
+    torch.manual_seed(B + ci + co + H + W)
+    x = torch.randn(B, ci, H, W, device="cuda").contiguous(memory_format=CL)
+    w = torch.randn(co, ci, 1, 1, device="cuda").contiguous(memory_format=CL)
+    resid = torch.randn(B, co, H, W, device="cuda").contiguous(memory_format=CL) if with_resid else None
+    L = plan_fwd(x.shape, w, ConvGeom(1, 1, 1, 0, False))
+    # (every case is a geometry ideas_b3_pw_ok takes: 1x1 / stride 1, Cin % 16 == 0 up to 128, or Cin % 128 == 0 with the residual)
+    M, guard = B * H * W, 512
+    poison = torch.full((M + 2 * guard, co), 0, device="cuda", dtype=torch.int32)
+    poison.fill_(0x7fc0dead)
+    big = poison.clone()
+    y = big[guard:guard + M].view(torch.float32).view(B, H, W, co).permute(0, 3, 1, 2)
+    assert y.is_contiguous(memory_format=CL) and y.data_ptr() == big.data_ptr() + guard * co * 4
+    CV.launch_fwd(y, x, L, 0.11, resid=resid, resid_gain=0.7)
+    torch.cuda.synchronize()
+    assert torch.equal(big[:guard], poison[:guard]) and torch.equal(big[guard + M:], poison[guard + M:]), case
+    ref = CV.conv_fwd_raw(x, w, ConvGeom(1, 1, 1, 0, False), 0.11, resid=resid, resid_gain=0.7)
+    assert torch.equal(y, ref)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 128, 16, 16), (3, 128, 64, 9, 14), (1, 256, 128, 24, 24), (5, 512, 512, 8, 8), (2, 64, 64, 33, 17)])

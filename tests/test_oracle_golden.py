@@ -41,6 +41,35 @@ def test_fused_leaky_relu(ops_golden, tag):
     assert rel_err(ggy, g.t(f"{tag}.ggy")) < 1e-6
 
 
+@pytest.mark.parametrize("tag", ["slr4", "slr2"])
+def test_scaled_leaky_relu(tag):
+    """ScaledLeakyReLU (stylegan2/model.py:169-178) -- the oracle's bias-free activation branch (oracle/torch_ref.py::conv_layer)
+    on the reference's vectors (tests/golden/ops_r06.npz): forward bit-exact, gradient, gradient of the gradient."""
+    g = Golden("ops_r06.npz")
+    x = g.t(f"{tag}.x").requires_grad_(True)
+    y = torch.nn.functional.leaky_relu(x, 0.2) * O.SQRT2
+    assert torch.equal(y, g.t(f"{tag}.y"))
+    gy = g.t(f"{tag}.gy").requires_grad_(True)
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    assert torch.equal(gx, g.t(f"{tag}.gx"))
+    (ggy,) = torch.autograd.grad((gx * g.t(f"{tag}.ggx")).sum(), gy)
+    assert torch.equal(ggy, g.t(f"{tag}.ggy"))
+
+
+@pytest.mark.parametrize("tag,kw", [("cl_slr", {}), ("cl_slr_down", {"downsample": True}), ("cl_slr_reflect", {"padding": "reflect"})])
+def test_conv_layer_with_scaled_leaky_relu(tag, kw):
+    """ConvLayer(bias=False, activate=True) (models.py:125-131): the only place the layer library reaches ScaledLeakyReLU."""
+    g = Golden("ops_r06.npz")
+    P = {f"L.{k}": g.t(f"{tag}.sd/{k}").requires_grad_(not k.endswith("kernel")) for k in g.json(f"{tag}.keys")}
+    x = g.t(f"{tag}.x").requires_grad_(True)
+    y = O.conv_layer(P, "L", x, 3, bias=False, activate=True, **kw)
+    assert rel_err(y, g.t(f"{tag}.y")) < 1e-6
+    wkey = [k for k in P if k.endswith("weight")][0]
+    gx, gw = torch.autograd.grad(y, (x, P[wkey]), g.t(f"{tag}.gy"))
+    assert rel_err(gx, g.t(f"{tag}.gx")) < 1e-5
+    assert rel_err(gw, g.t(f"{tag}.g/{wkey[2:]}")) < 1e-5
+
+
 def test_upfirdn2d_all_cases(ops_golden):
     g = ops_golden
     k1 = O.make_kernel((1, 3, 3, 1))
