@@ -631,7 +631,9 @@ def finish_extraction(e, f32: bool):
         e["oracle_image0"] = {"bits": int(m_ref.numel()), "decisions_equal_oracle": flipped == 0, "bits_flipped": flipped,
                               "hat_Z_rel_err": float("%.3g" % float((z_gpu - z_ref).abs().max() / z_ref.abs().max())),
                               "acc_oracle": round(d["acc"], 5), "acc_gpu": round(float(1 - (m_gpu - m0).abs().mean()), 5),
-                              "min_abs_hat_Z": float("%.3g" % float(z_ref.abs().min())),
+                              "min_abs_hat_Z": float("%.3g" % float(z_ref.abs().min())), "max_abs_hat_Z": float("%.3g" % float(z_ref.abs().max())),
+                              # (bf16 policy, DESIGN 3.6: a flipped bit must sit at the decision boundary -- |hat_Z| of every flipped bit, oracle's value)
+                              "abs_hat_Z_of_flipped_bits": [float("%.3g" % v) for v in z_ref.flatten()[(m_ref != m_gpu).flatten()].abs().tolist()][:16],
                               "oracle": "oracle/torch_ref.py::extraction_test (f32, CPU, %d threads) on the same EMA weights, message, jitter, "
                                         "texture code" % threads + ("" if f32 else "; this run is bf16 mixed precision: flipped bits are reported, not promised zero")}
     finally:
