@@ -55,7 +55,9 @@ class NormalDataset(data.Dataset):
 
 
 class LMDBDataset(data.Dataset):
-    """LMDB of encoded images (dataset.py:10-47).  Needs the ``lmdb`` package (not in the build image: raises clearly)."""
+    """LMDB of encoded images (dataset.py:10-47).  Needs the ``lmdb`` package (not in the build image: raises clearly).  Executed in
+    the tests against an in-process stand-in of that API (tests/lmdb_standin.py) -- beside the reference's own class on the same
+    store (tests/test_data.py); the LMDB file format itself is the package's business, not this class's."""
 
     def __init__(self, path: str, resolution: int = 256, max_num: int = 70000):
         try:

@@ -500,18 +500,28 @@ def path_length_step(trainer, args, batch: int, image_size: int, device, Z: Opti
 
 @torch.no_grad()
 def extraction_test(trainer, args, X: torch.Tensor, M: torch.Tensor, T2: torch.Tensor, use_x3: bool,
-                    jitter: Optional[torch.Tensor] = None, ema: bool = True):
-    """The sender/receiver block of train.py:249-286: bits -> Z -> S2 -> image -> S2' -> Z' -> bits."""
+                    jitter: Optional[torch.Tensor] = None, ema: bool = True, want_sample: bool = False):
+    """The sender/receiver block of train.py:249-286: bits -> Z -> S2 -> image -> S2' -> Z' -> bits.  ``want_sample``: also return
+    the sample sheet of train.py:293 -- ``cat(X, G(S1,T1), G(S2,T1), G(S2,T2))`` -- as a fifth value (all three syntheses are then
+    evaluated, as the reference does at :265-267; without it only the container image is)."""
     sfx = "_ema" if ema else ""
     E, G, Gs, Ex = (trainer[n + sfx] for n in ("E", "G", "Gstru", "Ex"))
     S1, T1 = E(X)
     Z = message_to_tensor(M, sigma=1, delta=0.5, jitter=jitter).to(X.device)
     Z = Z.reshape(S1.shape[0], args.N, S1.shape[2], S1.shape[3])
     S2 = Gs(Z)
-    container = G(S2, T2 if use_x3 else T1)
+    sample = None
+    if want_sample:
+        hat_X2, hat_X3 = G(S2, T1), G(S2, T2)
+        sample = torch.cat((X.float(), G(S1, T1).float(), hat_X2.float(), hat_X3.float()), 0)
+        container = hat_X3 if use_x3 else hat_X2
+    else:
+        container = G(S2, T2 if use_x3 else T1)
     hat_S2, _ = E(container)
     hat_Z = Ex(hat_S2)
     l1 = torch.mean(torch.abs(hat_Z - Z))
     hat_M = tensor_to_message(hat_Z.reshape(Z.shape[0], -1), sigma=1)
     acc = 1 - torch.mean(torch.abs(M.to(hat_M.device) - hat_M))
+    if want_sample:
+        return hat_Z, hat_M, acc, l1, sample
     return hat_Z, hat_M, acc, l1

@@ -67,6 +67,32 @@ def tensor_to_message(secret_tensor: torch.Tensor, sigma: int) -> torch.Tensor:
     return msg
 
 
+def image_grid(images: torch.Tensor, nrow: int, value_range=(-1.0, 1.0), padding: int = 2) -> torch.Tensor:
+    """uint8 [H', W', 3] grid of a [B, C, H, W] batch: what ``torchvision.utils.save_image(sample, path, nrow=..., normalize=True,
+    range=(-1, 1))`` writes for the sample sheet of train.py:295-303, restated (torchvision is not a dependency of this build):
+    clamp to the range, map it to [0, 1], lay the images out ``nrow`` per row with ``padding`` black pixels around each, then
+    ``* 255 + 0.5``, clamp and truncate to bytes."""
+    x = images.detach().float().cpu()
+    lo, hi = float(value_range[0]), float(value_range[1])
+    x = (x.clamp(min=lo, max=hi) - lo) / max(hi - lo, 1e-5)
+    b, c, h, w = x.shape
+    if c == 1:
+        x = x.expand(b, 3, h, w)
+    xmaps = min(int(nrow), b)
+    ymaps = -(-b // xmaps)
+    grid = torch.zeros(3, (h + padding) * ymaps + padding, (w + padding) * xmaps + padding)
+    for k in range(b):
+        y0, x0 = (k // xmaps) * (h + padding) + padding, (k % xmaps) * (w + padding) + padding
+        grid[:, y0:y0 + h, x0:x0 + w] = x[k]
+    return grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)
+
+
+def save_image_grid(images: torch.Tensor, path: str, nrow: int, value_range=(-1.0, 1.0)) -> None:
+    """Write the sample sheet (train.py:295-301): PNG by PIL, as torchvision's save_image does."""
+    from PIL import Image
+    Image.fromarray(image_grid(images, nrow, value_range).numpy()).save(path)
+
+
 def d_logistic_loss(real_pred, fake_pred):
     return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
 

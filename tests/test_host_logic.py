@@ -280,6 +280,27 @@ def test_checkpoint_fixture_is_the_file_the_reference_writes(tmp_path):
     assert sum(v.numel() for v in raw["trainer"]["Dreal"].values()) > 2e7
 
 
+def test_sample_sheet_layout_and_quantisation(tmp_path):
+    """ideas_amd.utils.save_image_grid = torchvision.utils.save_image(sample, path, nrow, normalize=True, range=(-1, 1)) of
+    train.py:295-301 (torchvision is absent here: its published make_grid / save_image arithmetic restated in numpy)."""
+    import numpy as np
+    from PIL import Image
+    from ideas_amd.utils import save_image_grid
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(7, 3, 5, 6, generator=g) * 0.8              # values outside [-1, 1] are clamped
+    path = str(tmp_path / "s.png")
+    save_image_grid(x, path, nrow=3)
+    got = np.asarray(Image.open(path))
+    n = ((x.clamp(-1, 1) + 1) / 2).numpy()
+    want = np.zeros((3 * 7 + 2, 3 * 8 + 2, 3), np.float32)          # ceil(7 / 3) = 3 rows, 3 columns, 2-pixel black padding
+    for k in range(7):
+        y0, x0 = (k // 3) * 7 + 2, (k % 3) * 8 + 2
+        want[y0:y0 + 5, x0:x0 + 6] = n[k].transpose(1, 2, 0)
+    want = np.clip(want * 255 + 0.5, 0, 255).astype(np.uint8)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert got[0, 0].tolist() == [0, 0, 0] and got[-1, -1].tolist() == [0, 0, 0]       # the empty ninth cell stays black too
+
+
 def test_derived_weight_cache_scope():
     """op/conv_plan.py cache: off by default (plain op calls never see stale derived weights), memoises only (views of)
     Parameters while on, and is emptied by cache_clear() -- which train_step._step calls after every optimiser step with that

@@ -29,6 +29,9 @@ def test_train_cli_runs_logs_saves_and_resumes(tmp_path):
     assert "[Testing 0000003/0000004] sigma=1 delta=50%" in log and "ACC of Msg:" in log
     ckpt = tmp_path / "experiments/t0/checkpoints/4.pt"            # the reference's file name (train.py:320)
     assert ckpt.exists()
+    sheet = Image.open(tmp_path / "experiments/t0/samples/0000003.png")      # train.py:295-301: 4 rows (X, hat_X1..3) of batch_size images
+    assert sheet.size == (4 * (64 + 2) + 2, 4 * (64 + 2) + 2) and sheet.mode == "RGB"
+    assert "Sample images are saved in experiments/t0/samples" in r.stdout
     # resume by path into a new experiment ...
     r = subprocess.run(base + ["--exp_name", "t1", "--num_iters", "6", "--save_every", "100", "--ckpt", str(ckpt)],
                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)

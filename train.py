@@ -8,8 +8,8 @@ Same flags, same log lines, same checkpoint format; one process per GPU:
 
 What differs from the reference: the data loader hands uint8 images to the device and the transform runs
 there (ideas_amd/data.py); gradients are averaged across ranks by one RCCL all-reduce per optimiser group (ideas_amd/ddp.py);
-Adam + EMA are one fused launch per group (ideas_amd/optim.py); sample grids are not written (torchvision is not a
-dependency) -- the test line with ACC / L1 is.  Below 256x256 the co-occurrence discriminator cannot run (models.py:400);
+Adam + EMA are one fused launch per group (ideas_amd/optim.py); the sample sheet of train.py:293-303 is laid out and written by
+ideas_amd.utils.save_image_grid (torchvision is not a dependency).  Below 256x256 the co-occurrence discriminator cannot run (models.py:400);
 ``--no_dco`` trains without its terms, which is only meant for smoke runs.
 """
 import argparse
@@ -86,8 +86,10 @@ def main():
 
     base_dir = f"experiments/{args.exp_name}"
     ckpt_dir = f"{base_dir}/checkpoints"
+    sample_dir = f"{base_dir}/samples"
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
+        os.makedirs(sample_dir, exist_ok=True)
 
     precision.set_activation_dtype(args.precision)
     torch.manual_seed(args.seed)               # identical replicas on every rank
@@ -160,12 +162,15 @@ def main():
                 M = torch.randint(low=0, high=2, dtype=torch.float, size=(X.shape[0], args.N * s * s))
                 T2 = torch.rand(X.shape[0], args.texture_channel, device=device) * 2 - 1
                 use_x3 = iter_idx > args.num_iters * 0.8
-                _, _, acc, l1 = TS.extraction_test(trainer, args, X, M, T2, use_x3)
+                _, _, acc, l1, sample = TS.extraction_test(trainer, args, X, M, T2, use_x3, want_sample=True)
             line = (f"[Testing {iter_idx:07d}/{args.num_iters:07d}] sigma=1 delta=50% using synthesised image "
                     f"\\hatX_{3 if use_x3 else 2} ACC of Msg: {float(acc):.4f}; L1 loss of tensor: {float(l1):.4f}")
             print(line, flush=True)
             with open(f"{base_dir}/training_logs.txt", "a") as fp:
                 fp.write(line + "\n")
+            from ideas_amd.utils import save_image_grid                 # train.py:293-303: X / G(S1,T1) / G(S2,T1) / G(S2,T2), one row each
+            save_image_grid(sample, f"{sample_dir}/{iter_idx:07d}.png", nrow=int(args.batch_size), value_range=(-1, 1))
+            print(f"Sample images are saved in experiments/{args.exp_name}/samples", flush=True)
 
         if (iter_idx % args.save_every == 0 or iter_idx == args.num_iters) and rank == 0:    # train.py:308-322
             checkpoint.save(f"{ckpt_dir}/{iter_idx}.pt", trainer, args, iter_idx)   # the reference's file name
