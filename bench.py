@@ -206,15 +206,14 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
         peak, kern = PEAK_BF16_MFMA_TFLOPS, ("conv_bf16_wgrad3_kernel<true,false> (tap-fused 3x3: one DMA'd G row + one new X window row per step, nine taps on "
                                              "ds_read_b64_tr_b16 transpose reads at pixel offsets, one bf16 product per MFMA)")
     elif CV.MATH == _lib.F32_B3:
-        wino = CV.B3_WINO_WGRAD
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-        kern = ("conv_b3_wino_wgrad_kernel<2,2,2,2,true,false> + wino_wgrad_fold_kernel (Winograd-domain, 2/3 of the products; " if wino
-                else "conv_b3_wgrad3_kernel<1,true,false> (tap-fused 3x3, rolling activation window in LDS; ") + "exact 3-way bf16 split of both operands, 6 bf16 MFMA products per f32 product)"
+        kern = ("conv_b3_wgrad3_kernel<1,true,false> (tap-fused 3x3, rolling activation window in LDS; exact 3-way bf16 split of both operands, "
+                "6 bf16 MFMA products per f32 product)")
     else:
         peak, kern = PEAK_F32_MFMA_TFLOPS, "conv3x3_wino_wgrad_kernel / conv_wgrad_kernel (f32 MFMA)"
     elem = 2 if bf16 else 4
     traffic = note = None
-    if batch == 32 and (bf16 or (CV.MATH == _lib.F32_B3 and not CV.B3_WINO_WGRAD)):
+    if batch == 32 and (bf16 or CV.MATH == _lib.F32_B3):
         traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r05_pmc_bf16wg" if bf16 else "r05_pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, column strips x row ranges in "

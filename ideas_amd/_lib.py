@@ -91,7 +91,6 @@ _PROTOS = {
     "ideas_bf16_pack_weights_strided": (C.c_int, [_P, _P, _P] + [C.c_int] * 5 + [C.c_int64] * 4 + [_P]),
     "ideas_conv3x3_wino": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
     "ideas_conv3x3_wino_wgrad": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(ConvParams), C.c_int, _P]),
-    "ideas_b3_wino_wgrad_supported": (C.c_int, [C.POINTER(ConvParams)]),
     "ideas_wino_wgrad_fold": (C.c_int, [_P, _P, C.c_int, C.c_int] + [C.c_int64] * 4 + [C.c_int, _P]),
     "ideas_b3_blur_conv_s2_supported": (C.c_int, [C.POINTER(ConvParams), C.c_int, C.c_int, C.c_int]),
     "ideas_b3_blur_conv_s2": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, C.POINTER(ConvParams),

@@ -138,9 +138,7 @@ bool ideas_b3_wgrad3_enabled();
 // conv_b3_wino.hip: 3x3/s1/p1 Winograd F(2,3) with the split contraction (uplanes from ideas_b3_wino_split_weights)
 int ideas_b3_wino_fwd(void* y, const void* x, const void* uplanes, const float* in_scale, const float* out_scale,
                       const float* bias, const void* resid, const ideas_conv_params* p, hipStream_t stream);
-// conv_b3_wino_wgrad.hip: Winograd-domain weight gradient of the same layers with the split contraction (dU [4][Cout][3][Cin])
-int ideas_b3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale, const float* out_scale,
-                        const ideas_conv_params* p, hipStream_t stream);
+
 // conv_bf16.hip: bf16 mixed-precision family (dtype IDEAS_BF16): bf16 activations, packed bf16 weights (ideas_bf16_pack_weights)
 int ideas_bf16_fwd(void* y, const void* x, const void* wpack, int per_image, const float* out_scale, const float* bias,
                    const void* resid, const ideas_conv_params* p, hipStream_t stream);

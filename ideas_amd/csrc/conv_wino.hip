@@ -450,13 +450,6 @@ extern "C" int ideas_conv3x3_wino(void* y, const void* x, const void* umat, cons
 // plus Cout % 4 == 0.  in_scale / out_scale: both or neither.
 extern "C" int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale,
                                         const float* out_scale, const ideas_conv_params* p, int dtype, void* stream_) {
-    if (dtype == IDEAS_F32_B3) {   // split-bf16 contraction (conv_b3_wino_wgrad.hip), same dU layout
-        if (!gu || !gy || !x || !p) return IDEAS_E_NULL;
-        if ((in_scale == nullptr) != (out_scale == nullptr) || !ideas_b3_wino_wgrad_supported(p)) return IDEAS_E_UNSUPPORTED;
-        if (!ideas_aligned16(x) || !ideas_aligned16(gy) || (in_scale && (!ideas_aligned16(in_scale) || !ideas_aligned16(out_scale))))
-            return IDEAS_E_ALIGN;
-        return ideas_b3_wino_wgrad(gu, gy, x, in_scale, out_scale, p, (hipStream_t)stream_);
-    }
     if (dtype != IDEAS_F32) return IDEAS_E_UNSUPPORTED;
     if (!gu || !gy || !x || !p) return IDEAS_E_NULL;
     if (p->B <= 0 || p->IH <= 0 || p->IW <= 0 || p->Cin <= 0 || p->Cout <= 0) return IDEAS_E_SHAPE;
@@ -508,5 +501,37 @@ extern "C" int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x
     using F = std::false_type;
     if (in_scale) { if (p->reflect) go(T{}, T{}); else go(T{}, F{}); }
     else { if (p->reflect) go(F{}, T{}); else go(F{}, F{}); }
+    return ideas_launch_status();
+}
+
+namespace {
+// dU [4][Cout][3][Cin] -> the 3x3 taps, ADDED into gw (element (o, ky, kx, ci) at gw[o*so + ky*sky + kx*skx + ci*sc]); `clear`
+// re-zeroes dU behind the read so that the scratch is ready for the next weight gradient without a fill launch
+__global__ __launch_bounds__(256) void wino_wgrad_fold_kernel(float* __restrict__ gw, float* __restrict__ gu, int Cout, int Cin,
+                                                              int64_t so, int64_t sky, int64_t skx, int64_t sc, int clear) {
+    const int64_t n = (int64_t)Cout * 3 * Cin;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int ci = (int)(i % Cin);
+        const int ky = (int)((i / Cin) % 3);
+        const int o = (int)(i / (3 * (int64_t)Cin));
+        const float u0 = gu[i], u1 = gu[n + i], u2 = gu[2 * n + i], u3 = gu[3 * n + i];
+        if (clear) { gu[i] = 0.f; gu[n + i] = 0.f; gu[2 * n + i] = 0.f; gu[3 * n + i] = 0.f; }
+        const float half = (u1 + u2) * 0.5f;
+        float* d = gw + o * so + ky * sky + ci * sc;
+        d[0] += u0 + half;
+        d[skx] += (u1 - u2) * 0.5f;
+        d[2 * skx] += half + u3;
+    }
+}
+}  // namespace
+
+extern "C" int ideas_wino_wgrad_fold(float* gw, float* gu, int Cout, int Cin, int64_t so, int64_t sky, int64_t skx, int64_t sc,
+                                     int clear, void* stream_) {
+    if (!gw || !gu) return IDEAS_E_NULL;
+    if (Cout <= 0 || Cin <= 0) return IDEAS_E_SHAPE;
+    const int64_t n = (int64_t)Cout * 3 * Cin;
+    const int blocks = (int)(ideas_cdiv(n, 256) < 4096 ? ideas_cdiv(n, 256) : 4096);
+    hipLaunchKernelGGL(wino_wgrad_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, gw, gu, Cout, Cin, so, sky, skx, sc,
+                       clear);
     return ideas_launch_status();
 }

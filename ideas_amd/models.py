@@ -28,10 +28,6 @@ from .precision import to_act, to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
 FUSE_RESIDUAL_ADDS = True     # big residual blocks: block input forked by one autograd node (gradient sum / merge add ride in kernels)
-# Dco: one encoder pass over fake + real + reference patches instead of three.  Measured (same box, tools/ab_step.sh): f32 450.8 ->
-# 454.5 ms, bf16 162.3 -> 161.7 ms -- the 32B-patch pass already fills the chip and the merged pass loses the overlap of one pass's
-# weight gradients (side stream) with the next pass's forward.  OFF by default; IDEAS_BATCH_DCO=1 selects it.
-BATCH_DCO = os.environ.get("IDEAS_BATCH_DCO", "0") == "1"
 FUSE_BLUR_CONV = os.environ.get("IDEAS_BLUR_CONV", "1") != "0"   # downsampling ResBlock body with conv2's Blur inside its conv kernel
 FUSE_BLUR_BACKWARD = True     # ResBlock: conv1 + conv2's Blur as one Function whose backward is one kernel (A/B switch for tools / tests)
 
@@ -410,12 +406,10 @@ class CooccurenceDiscriminator(nn.Module):
         )
 
     def encode_many(self, *batches):
-        """ONE encoder pass over several patch batches.  The encoder has no cross-sample op, so every sample's features are those
-        of a separate pass; the late layers (2x2 .. 8x8 pixels per patch) get 48B instead of 8B samples per launch and a third of
-        the launches (see BATCH_DCO: no gain measured, off by default -> separate passes)."""
-        if len(batches) == 1 or not BATCH_DCO:
-            return tuple(self.encoder(b) for b in batches)
-        return self.encoder(torch.cat(batches, 0)).split([b.shape[0] for b in batches], 0)
+        """One encoder pass per patch batch.  (ONE pass over the concatenated batches was measured in round 3 -- f32 450.8 -> 454.5 ms,
+        bf16 162.3 -> 161.7 ms: the 32B-patch pass already fills the chip and the merged pass loses the overlap of one pass's
+        weight gradients with the next pass's forward -- and removed in round 6.)"""
+        return tuple(self.encoder(b) for b in batches)
 
     @staticmethod
     def _ref_mean(ref, ref_batch):
@@ -433,7 +427,7 @@ class CooccurenceDiscriminator(nn.Module):
 
     def forward_pair(self, fake, real, reference, ref_batch):
         """``(forward(fake, reference, ref_batch)[0], forward(real, ref_input=...)[0], ref_input)`` -- the two calls of the D phase
-        (train.py:88-90) -- with one encoder pass over fake, real and reference patches and one pass of the linear head."""
+        (train.py:88-90) -- with one pass of the linear head over both (the encoder runs per batch, see encode_many)."""
         out_f, out_r, ref = self.encode_many(fake, real, reference)
         ref_input = self._ref_mean(ref, ref_batch)
         both = torch.flatten(torch.cat((torch.cat((out_f, out_r), 0), torch.cat((ref_input, ref_input), 0)), 1), 1)

@@ -344,17 +344,11 @@ def conv_dgrad_fold32(gxp: torch.Tensor, in_hw, pad: int) -> torch.Tensor:
     return gx.to(BF)
 
 
-# Winograd-domain weight gradient of the split-bf16 path (csrc/conv_b3_wino_wgrad.hip): 2/3 of the products, but measured no
-# faster than the direct split weight-gradient kernel (the step is bound by operand staging, not by the matrix pipe: 159-199
-# against 161-184 TFLOP/s on the 128-512 channel layers, slower below; profiles/r02_wgrad_ab.txt), so it is OFF by default;
-# IDEAS_B3_WINO_WGRAD=1 selects it for the 3x3/s1 layers it supports.
-B3_WINO_WGRAD = _os.environ.get("IDEAS_B3_WINO_WGRAD", "0") == "1"
 _GU = {}
 
 
 def _wino_gu_scratch(n: int, device) -> torch.Tensor:
-    """ZEROED f32 scratch for the Winograd-domain gradient dU, one per (stream, size): the fold kernel re-zeroes it behind its
-    read, so it is filled once and never again.  Keyed by stream because the gradient sink runs weight gradients on its own."""
+    """ZEROED f32 scratch for a Winograd-domain gradient dU, one per (stream, size) (a fold with ``clear`` re-zeroes it behind its read)."""
     key = (_lib.stream_ptr(), n, str(device))
     buf = _GU.get(key)
     if buf is None:
@@ -371,45 +365,7 @@ def _wino_fold(gu, out, co: int, ci: int, w_shape, device, clear: bool = True):
     return tgt
 
 
-# Weight gradients of the layers with <= 4x4 output pixels per sample and many samples (the co-occurrence discriminator's last
-# blocks: 1024 patches of 2x2 .. 4x4).  Round 3 sent them to ONE library GEMM [Cout, P] x [P, KH*KW*Cin] (hipBLASLt) on a materialised
-# im2col (one cat of the KH*KW shifted views of the padded NHWC tensor), because conv_bf16_wgrad_kernel did not cover images narrower
-# than its 32-pixel K-step and those layers fell to the f32 kernels behind casts (50-140 TFLOP/s).  Round 4: the kernel's K-step
-# advances by whole samples when the image size divides 32 (csrc/conv_bf16.hip), every pixel of a step is a real output pixel, and
-# it beats the GEMM on every shape of tools/tiny_wgrad_scan.py (1024 x 2x2 768->768: 0.095 against 0.176 ms; 1024 x 4x4 384->384:
-# 0.095 / 0.263; 256 x 2x2 384->768: 0.040 / 0.075) without the cat / pad composites.  Default 0 = the HIP kernels;
-# IDEAS_TINY_WGRAD_GEMM=1: the GEMM for bf16 activations (A/B), 2: f32 too (tests/test_bf16_gpu.py runs both against f64).
-TINY_WGRAD_GEMM = int(_os.environ.get("IDEAS_TINY_WGRAD_GEMM", "0"))
 PRESCALE_MOD_PIX = int(_os.environ.get("IDEAS_PRESCALE_MOD_PIX", "256"))
-TINY_MAX_PIX = int(_os.environ.get("IDEAS_TINY_MAX_PIX", "16"))
-TINY_MAX_PIX_MOD = int(_os.environ.get("IDEAS_TINY_MAX_PIX_MOD", "16"))
-
-
-def _tiny_spatial_wgrad(gy, x, g: ConvGeom, w_shape, gain: float, out, lin=None, lout=None):
-    b, co, oh, ow = gy.shape
-    ci, kh, kw, st = x.shape[1], w_shape[2], w_shape[3], g.stride
-    xn = x.permute(0, 2, 3, 1)                                    # NHWC view of the channels_last tensor
-    gn = gy.permute(0, 2, 3, 1)
-    if lin is not None:                                           # per-sample scales: applied in f32, rounded once
-        xn = (xn * lin[:, None, None, :].float()).to(x.dtype)
-        gn = (gn * lout[:, None, None, :].float()).to(gy.dtype)
-    if g.pad:
-        xn = torch.nn.functional.pad(xn, (0, 0, g.pad, g.pad, g.pad, g.pad))
-    cols = torch.cat([xn[:, ky:ky + st * (oh - 1) + 1:st, kx:kx + st * (ow - 1) + 1:st, :] for ky in range(kh) for kx in range(kw)], dim=3)
-    g2 = gn.reshape(b * oh * ow, co)
-    x2 = cols.reshape(b * oh * ow, kh * kw * ci)
-    if g2.dtype == torch.float32:
-        res = torch.mm(g2.t(), x2)
-    else:
-        try:
-            res = torch.mm(g2.t(), x2, out_dtype=torch.float32)
-        except (TypeError, RuntimeError, NotImplementedError):
-            res = torch.mm(g2.t().float(), x2.float())
-    if out is not None and tuple(out.shape) == tuple(w_shape) and out.is_contiguous(memory_format=CL):
-        out.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).add_(res, alpha=gain)          # (a view: OHWI memory)
-        return out
-    gw = (res * gain).view(co, kh, kw, ci).permute(0, 3, 1, 2)
-    return gw if out is None else out.add_(gw)
 
 
 def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None, out=None):
@@ -425,10 +381,6 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         else:
             lout = torch.ones((gy.shape[0], gy.shape[1]), device=x.device, dtype=torch.float32)
     L = plan_wgrad(x.shape, gy.shape, g)
-    if TINY_WGRAD_GEMM and (x.dtype == torch.bfloat16 or TINY_WGRAD_GEMM > 1) and not g.reflect \
-            and gy.shape[2] * gy.shape[3] <= (TINY_MAX_PIX if lin is None else TINY_MAX_PIX_MOD) \
-            and gy.shape[0] * gy.shape[2] * gy.shape[3] >= 512 and x.shape[1] >= 64 and gy.shape[1] >= 64:
-        return _tiny_spatial_wgrad(gy, x, g, w_shape, gain, out, lin, lout)
     if x.dtype == BF and lin is not None and gy.shape[2] * gy.shape[3] <= PRESCALE_MOD_PIX:
         # small images of a modulated layer (bf16): the kernels apply the per-sample scales to the accumulators, so a split-K block
         # cannot cross a sample and a 16x16 image gives each block 8 K-steps under a 128x128 atomic epilogue (145 TFLOP/s).
@@ -436,29 +388,17 @@ def conv_wgrad_raw(gy, x, g: ConvGeom, w_shape, gain: float, lin=None, lout=None
         x = (x * lin[:, :, None, None]).to(BF)
         gy = (gy * lout[:, :, None, None]).to(BF)
         lin = lout = None
-    if x.dtype == torch.float32 and MATH == _lib.F32_B3 and B3_WINO_WGRAD and tuple(w_shape[2:]) == (3, 3) and g.stride == 1 \
-            and g.pad == 1:
-        b, ci, h, wd = x.shape
-        co = gy.shape[1]
-        p = _lib.ConvParams(b, h, wd, ci, h, wd, co, h, wd, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(g.reflect), 0, 0.2,
-                            1.0, 1.0, 0, gain)
-        if _lib.load().ideas_b3_wino_wgrad_supported(C.byref(p)):
-            gu = _wino_gu_scratch(4 * co * 3 * ci, x.device)
-            rc = _lib.load().ideas_conv3x3_wino_wgrad(_lib.ptr(gu), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(lin), _lib.ptr(lout),
-                                                      C.byref(p), _lib.F32_B3, _lib.stream_ptr())
-            _lib.check(rc, "ideas_conv3x3_wino_wgrad[b3]")
-            return _wino_fold(gu, out, co, ci, w_shape, x.device)
     b3 = x.dtype == BF or (MATH == _lib.F32_B3 and bool(_lib.load().ideas_b3_wgrad_supported(C.byref(_params(L, gain)))))
     if not b3 and _wino_ok(g, x.shape[1], x.shape[3], fwd=False) and gy.shape[1] % 4 == 0 and tuple(w_shape[2:]) == (3, 3):
         b, ci, h, wd = x.shape
         co = gy.shape[1]
-        gu = torch.zeros((4, co, 3, ci), device=x.device, dtype=torch.float32)
+        gu = _wino_gu_scratch(4 * co * 3 * ci, x.device)          # zeroed once; the fold re-zeroes it behind its read
         p = _lib.ConvParams(b, h, wd, ci, h, wd, co, h, wd, 3, 3, 1, 1, 1, 1, -1, -1, 1, 1, 0, 0, int(g.reflect), 0, 0.2,
                             1.0, 1.0, 0, gain)
         rc = _lib.load().ideas_conv3x3_wino_wgrad(_lib.ptr(gu), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(lin), _lib.ptr(lout),
                                                   C.byref(p), _lib.F32, _lib.stream_ptr())
         _lib.check(rc, "ideas_conv3x3_wino_wgrad")
-        return _wino_fold(gu, out, co, ci, w_shape, x.device, clear=False)
+        return _wino_fold(gu, out, co, ci, w_shape, x.device, clear=True)
     if (lin is None) != (lout is None):   # the MFMA wgrad kernel takes both per-sample scales or neither
         if lin is None:
             lin = torch.ones((x.shape[0], x.shape[1]), device=x.device, dtype=torch.float32)

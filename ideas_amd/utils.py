@@ -106,7 +106,6 @@ def g_nonsaturating_loss(fake_pred):
     return F.softplus(-fake_pred).mean()
 
 
-_PATCHIFY_HIP = os.environ.get("IDEAS_PATCHIFY_HIP", "1") != "0"      # 0: one F.interpolate per box (A/B only)
 
 
 def draw_boxes(height: int, width: int, n_crop: int, min_size: float = 1 / 8, max_size: float = 1 / 4) -> List[Box]:
@@ -125,9 +124,13 @@ def patchify_image(img: torch.Tensor, n_crop: int, min_size: float = 1 / 8, max_
     if boxes is None:
         boxes = draw_boxes(h, w, n_crop, min_size, max_size)
     th, tw = int(h * max_size), int(w * max_size)
-    if img.is_cuda and c in (1, 3) and len(boxes) <= 64 and _PATCHIFY_HIP:      # one launch for all boxes (csrc/patchify.hip)
-        from .op.patchify import patch_resize
+    if img.is_cuda:
+        if c not in (1, 3) or len(boxes) > 64:                # (train.py never asks for it: RGB images, 8 or 32 boxes)
+            raise RuntimeError(f"patchify_image on a device tensor: csrc/patchify.hip covers 1 or 3 channels and <= 64 boxes, got {c} / "
+                               f"{len(boxes)} (no eager fallback on the device)")
+        from .op.patchify import patch_resize                 # one launch for all boxes
         return patch_resize(img, boxes, (th, tw))
+    # host tensors only: the restatement of utils.py:141-147 that the CPU host-logic tests drive the step with
     patches = [F.interpolate(img[:, :, y:y + ch, x:x + cw], size=(th, tw), mode="bilinear", align_corners=False)
                for (y, x, ch, cw) in boxes]
     return torch.stack(patches, 1).reshape(-1, c, th, tw)

@@ -15,8 +15,7 @@
  *     besides its arguments is a handful of A/B measurement switches in the process environment, looked up PER CALL (nothing is
  *     cached in the library): IDEAS_B3_WINO2D, IDEAS_B3_TPHASE, IDEAS_B3_WGRAD3, IDEAS_B3_WGRAD3_S2, IDEAS_S2FIR_CFG,
  *     IDEAS_BF16_IMG, IDEAS_BF16_WGRAD3, IDEAS_B3_PW, IDEAS_B3_PW_WGRAD, IDEAS_BF16_PW, IDEAS_B3_WINO_EPI, IDEAS_S2IMG_MIN_BLOCKS
- *     -- each "0" selects the older kernel of its family, unset = the default dispatch (IDEAS_B3_WGRAD3_S2=2: the opt-in
- *     two-rows-per-step variant).
+ *     -- each "0" selects the older kernel of its family, unset = the default dispatch.
  *     What IS memoised per process: immutable device properties (the CU count and the occupancy hipOccupancy... reports for the
  *     library's own split-K kernels), used to size grids;
  *   - return value: 0 = enqueued; negative = argument error (IDEAS_E_*); positive = hipError_t of the launch.
@@ -269,14 +268,12 @@ int ideas_conv3x3_wino(void* y, const void* x, const void* umat, const float* in
  * dw[kx=0] = dU0 + (dU1+dU2)/2, dw[kx=1] = (dU1-dU2)/2, dw[kx=2] = (dU1+dU2)/2 + dU3.  Cout % 4 == 0 as well. */
 int ideas_conv3x3_wino_wgrad(float* gu, const void* gy, const void* x, const float* in_scale, const float* out_scale,
                              const ideas_conv_params* p, int dtype, void* stream);
-/* dtype IDEAS_F32_B3 of the call above (csrc/conv_b3_wino_wgrad.hip: the same dU from the split-bf16 contraction, 2/3 of the
- * direct split kernel's products) covers what ideas_b3_wino_wgrad_supported accepts: IW % 8 == 0, IW/2 a divisor or a multiple
- * of 16, B*IH*IW/2 % 16 == 0 and >= 16384, Cout > 32, Cin % 4 == 0, Cout % 4 == 0, tensors < 4 GiB.
+/* (dtype IDEAS_F32 only: the split-bf16 form of this call, measured no faster than the direct split weight gradient in rounds 2-5,
+ * left the library in round 6 -- tools/attic/conv_b3_wino_wgrad.hip.)
  * ideas_wino_wgrad_fold ADDS the folded taps to gw -- element (o, ky, kx, ci) at gw[o*so + ky*sky + kx*skx + ci*sc] (floats), so
  * the OHWI gradient of a parameter or a strided view of a flat gradient bucket -- and, with `clear`, re-zeroes dU behind the
  * read (a persistent scratch then never needs a fill launch).  Replaces the autograd weight gradient of the F.conv2d calls at
  * stylegan2/model.py:115-121 (EqualConv2d) and :262-277 (ModulatedConv2d, same-resolution branch) for the 3x3 layers. */
-int ideas_b3_wino_wgrad_supported(const ideas_conv_params* p);
 int ideas_wino_wgrad_fold(float* gw, float* gu, int Cout, int Cin, int64_t so, int64_t sky, int64_t skx, int64_t sc, int clear,
                           void* stream);
 

@@ -90,10 +90,9 @@ def test_cooccurrence_discriminator(nets_golden):
     _check(nets_golden, "Dco", net, fwd=lambda a, r: net(a, r, ref_batch=2)[0], r1_input=0)
 
 
-def test_cooccurrence_discriminator_batched_encoder(nets_golden, monkeypatch):
-    """``forward_pair`` (one encoder pass over fake + real + reference patches: the D phase of the product's step) against the
-    reference's two calls with separate encoder passes (train.py:88-90): logits, reference features, parameter and input gradients."""
-    import ideas_amd.models as M
+def test_cooccurrence_discriminator_forward_pair(nets_golden):
+    """``forward_pair`` (the D phase of the product's step: one pass of the linear head over the fake and the real logits) against the
+    reference's two calls (train.py:88-90): logits, reference features, parameter and input gradients."""
     net = _load(nets_golden, "Dco", "CooccurenceDiscriminator", tiny(256))
     torch.manual_seed(11)
     fake = torch.randn(4, 3, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
@@ -106,11 +105,9 @@ def test_cooccurrence_discriminator_batched_encoder(nets_golden, monkeypatch):
         b, _ = net(real, ref_input=ri)
         return a, b, ri
 
-    monkeypatch.setattr(M, "BATCH_DCO", False)
     a0, b0, r0 = two_calls()
     g0 = torch.autograd.grad((a0 * 1.5).sum() - b0.sum(), [fake] + params)
-    monkeypatch.setattr(M, "BATCH_DCO", True)
-    for fn in (two_calls, lambda: net.forward_pair(fake, real, ref, 2)):
+    for fn in (lambda: net.forward_pair(fake, real, ref, 2),):
         a1, b1, r1 = fn()
         assert rel_err(a1, a0) < 1e-5 and rel_err(b1, b0) < 1e-5 and rel_err(r1, r0) < 1e-5
         g1 = torch.autograd.grad((a1 * 1.5).sum() - b1.sum(), [fake] + params)
