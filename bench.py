@@ -415,14 +415,15 @@ def _pmc_traffic(kernel_substr: str, prefix: str, smallest_grid: bool = False):
 
 
 def eager_complete(a):
-    """Complete eager iterations at the headline shape (tools/eager_cached.sh): profiles/r04_eager_full.json -- MIOpen's default find
+    """Complete eager iterations at the headline shape (tools/eager_cached.sh): profiles/r06_eager_full.json (round 6's re-measurement
+    from the committed find-db; r04_eager_full.json is round 4's) -- MIOpen's default find
     mode, every convolution searched once and then served from the find-db -- when it exists, else profiles/r04_eager_fast.json --
     MIOPEN_FIND_MODE=FAST, the immediate-mode solver choice without a search.  Used only while the sidecar matches: same torch
     build, same oracle / comparator sources, same batch -- otherwise stale -> None."""
     import hashlib
     src = b"".join(open(os.path.join(ROOT, f), "rb").read() for f in ("oracle/torch_ref.py", "tests/eager_baseline.py"))
     sha = hashlib.sha256(src).hexdigest()[:16]
-    for name in ("r04_eager_full.json", "r04_eager_fast.json"):
+    for name in ("r06_eager_full.json", "r04_eager_full.json", "r04_eager_fast.json"):      # newest measurement first
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             if d["source_sha16"] != sha or d["torch_version"] != torch.__version__ or d["batch"] != a.batch:

@@ -28,7 +28,7 @@ try:
     d.update(torch_version=torch.__version__, source_sha16=hashlib.sha256(src).hexdigest()[:16],
              miopen="default solvers (cudnn.benchmark False), kernels precompiled over several calls (tools/eager_cached.sh)",
              device=torch.cuda.get_device_name(0))
-    json.dump(d, open("$R/gpurun_out/r04_eager_full.json", "w"), indent=1)
+    json.dump(d, open("$R/gpurun_out/${IDEAS_ROUND:-r06}_eager_full.json", "w"), indent=1)
     print(json.dumps(d))
 except Exception as e:
     print("no result: %s" % e)
