@@ -101,11 +101,12 @@ def main():
         return log, flat, {k: tr[k].flat_g.data_ptr() for k in ("d_optim", "g_optim", "ex_optim")}
 
     def dist_of(a, b):
-        """(relative gradient difference at the first optimiser step, worst over the later ones, fraction of parameters differing by > 1e-6)"""
+        """(relative gradient difference at the first optimiser step, worst over the later ones, largest and mean |difference| of the
+        final parameters)"""
         (la, fa, _), (lb, fb, _) = a, b
         assert [t for t, _ in la] == [t for t, _ in lb] == ["d", "g", "ex", "d", "r1", "g", "ex"], [t for t, _ in la]
         errs = [float((x - y).abs().max() / y.abs().max().clamp_min(1e-30)) for (_, x), (_, y) in zip(la, lb)]
-        return errs[0], max(errs[1:]), float(((fa - fb).abs() > 1e-6).float().mean())
+        return errs[0], max(errs[1:]), float((fa - fb).abs().max()), float((fa - fb).abs().mean())
 
     base1, base2 = run(False), run(False)
     n0 = len(calls)
@@ -119,15 +120,17 @@ def main():
     assert {p for _, _, _, p in ar} == set(red[2].values()), "all-reduce ran on something else than the optimisers' flat gradient buffers"
 
     # (2) same numbers as without a reducer.  The first optimiser step sees identical weights: only the atomics' order differs
-    # (bound: 4x what two reducer-less runs show, floor 1e-5 / bf16 1e-3).  After it, Adam's first update is lr * sign(g): a
-    # noise-floor gradient of either sign moves its weight by +-lr, so later gradients agree to the bound the 2-rank gloo worker uses
-    # (3e-2 / 5e-2) and a few parameters in a thousand differ -- two reducer-less runs do the same (printed beside).
+    # (bound: 4x what two reducer-less runs show, floor 1e-5 / bf16 1e-3).  After it, Adam's update with beta1 = 0 is lr * g / (|g| + eps):
+    # a gradient element at the noise floor moves its weight by up to +-lr either way, so later gradients agree to the bound the 2-rank
+    # gloo worker uses (3e-2 / 5e-2), and a final parameter can differ by at most 2 * lr per optimiser step it saw (three for the D
+    # group) -- a few per cent of them do, depending on how the atomics happened to interleave (two reducer-less runs printed beside:
+    # back to back they interleave almost identically, so that pair UNDERSTATES the spread and is not used as the bound here).
     def check(r, what):
-        first, later, frac = dist_of(r, base1)
+        first, later, pmax, pmean = dist_of(r, base1)
         assert first <= max(4 * noise[0], 1e-3 if bf16 else 1e-5), (what, first, noise)
         assert later <= (5e-2 if bf16 else 3e-2), (what, later, noise)
-        assert frac <= max(4 * noise[2], 2e-2), (what, frac, noise)
-        return first, later, frac
+        assert pmax <= 3 * 2 * args.lr * 1.01 and pmean <= 1e-3, (what, pmax, pmean, noise)
+        return first, later, pmax, pmean
     got = check(red, "reducer")
     # (3) reproducible next to other work, three times
     for k in range(3):
@@ -136,7 +139,7 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print("one-rank RCCL ok: 7 all-reduces per two iterations; vs reducer-less run: first-step gradient %.2e (run-to-run %.2e), later steps %.2e (%.2e), "
-          "parameters differing %.2e (%.2e)" % (got[0], noise[0], got[1], noise[1], got[2], noise[2]), flush=True)
+          "final parameters max |diff| %.2e (%.2e), mean %.2e (%.2e)" % (got[0], noise[0], got[1], noise[1], got[2], noise[2], got[3], noise[3]), flush=True)
 
 
 if __name__ == "__main__":
