@@ -115,15 +115,55 @@ class EqualLinear(nn.Module):
         return f"{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})"
 
 
+class _ScaledLeakyReLUBackward(torch.autograd.Function):
+    """Gradient of ``leaky_relu(x, a) * s`` in AUTOGRAD'S order -- the reference's ScaledLeakyReLU is two torch ops
+    (stylegan2/model.py:175-178), so its gradient is ``leaky_relu_backward(g * s, x)`` = ``(x > 0 ? g s : (g s) a)``: scale first, then
+    the slope.  The fused op's kernel applies the slope first (fused_bias_act_kernel.cu:40-41), one rounding apart for x < 0; two
+    launches of the same kernel reproduce autograd's order bit for bit: ``g * s`` (forward mode, slope 1), then the mask with scale 1.
+    Its own gradient (w.r.t. g) is ``(mask * gg) * s`` -- the kernel's native order, which is also autograd's there."""
+
+    @staticmethod
+    def forward(ctx, grad_output, out, negative_slope, scale):
+        from .op.fused_act import bias_act_raw
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        gs = bias_act_raw(grad_output, None, None, 0, 1.0, scale)
+        return bias_act_raw(gs, None, out, 1, negative_slope, 1.0)
+
+    @staticmethod
+    def backward(ctx, gg):
+        from .op.fused_act import bias_act_raw
+        (out,) = ctx.saved_tensors
+        return bias_act_raw(gg, None, out, 1, ctx.negative_slope, ctx.scale), None, None, None
+
+
+class _ScaledLeakyReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, negative_slope, scale):
+        from .op.fused_act import bias_act_raw
+        out = bias_act_raw(input, None, None, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (out,) = ctx.saved_tensors          # sign(out) == sign(x): the mask of leaky_relu_backward
+        return _ScaledLeakyReLUBackward.apply(grad_output, out, ctx.negative_slope, ctx.scale), None, None
+
+
 class ScaledLeakyReLU(nn.Module):
-    """``leaky_relu(x) * sqrt(2)`` — the bias-free activation (not instantiated by any IDEAS net)."""
+    """``leaky_relu(x) * sqrt(2)`` — the bias-free activation (stylegan2/model.py:169-178; not instantiated by any IDEAS net): forward
+    on the fused kernel (select, multiply: the reference's op order, bit-exact), backward in autograd's op order (see above)."""
 
     def __init__(self, negative_slope=0.2):
         super().__init__()
         self.negative_slope = negative_slope
 
     def forward(self, input):
-        return fused_leaky_relu(input, None, self.negative_slope, math.sqrt(2))
+        from . import _lib
+        _lib.require_cuda(input)
+        return _ScaledLeakyReLU.apply(input, self.negative_slope, math.sqrt(2))
 
 
 def modconv_weight_layout(w5: torch.Tensor, upsample: bool) -> torch.Tensor:

@@ -122,13 +122,14 @@ def main():
     # (2) same numbers as without a reducer.  The first optimiser step sees identical weights: only the atomics' order differs
     # (bound: 4x what two reducer-less runs show, floor 1e-5 / bf16 1e-3).  After it, Adam's update with beta1 = 0 is lr * g / (|g| + eps):
     # a gradient element at the noise floor moves its weight by up to +-lr either way, so later gradients agree to the bound the 2-rank
-    # gloo worker uses (3e-2 / 5e-2), and a final parameter can differ by at most 2 * lr per optimiser step it saw (three for the D
+    # gloo worker uses (3e-2 / 5e-2; bf16 at this narrow width shows up to 7e-2 between two reducer-less runs: 4x that pair where it is
+    # larger), and a final parameter can differ by at most 2 * lr per optimiser step it saw (three for the D
     # group) -- a few per cent of them do, depending on how the atomics happened to interleave (two reducer-less runs printed beside:
     # back to back they interleave almost identically, so that pair UNDERSTATES the spread and is not used as the bound here).
     def check(r, what):
         first, later, pmax, pmean = dist_of(r, base1)
         assert first <= max(4 * noise[0], 1e-3 if bf16 else 1e-5), (what, first, noise)
-        assert later <= (5e-2 if bf16 else 3e-2), (what, later, noise)
+        assert later <= max(4 * noise[1], 5e-2 if bf16 else 3e-2), (what, later, noise)
         assert pmax <= 3 * 2 * args.lr * 1.01 and pmean <= 1e-3, (what, pmax, pmean, noise)
         return first, later, pmax, pmean
     got = check(red, "reducer")
