@@ -103,7 +103,7 @@ def roofline_probe_bf16(device, batch: int, launches: int):
     flops = 2.0 * batch * 256 * 256 * 128 * 128 * 9
     achieved = flops / (ms * 1e-3) / 1e12
     alg_bytes = 2.0 * batch * 256 * 256 * 128 * 2          # read x + write y, bf16
-    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "r05_pmc_bf16") if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("conv_bf16_img_kernel", "pmc_bf16") if batch == 32 else (None, None)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": note,
             "kernel": "conv_bf16_img_kernel<64,2,true> (the activation operand as an LDS image: one DMA of the 6 x 66 input pixels per 32-channel "
@@ -150,7 +150,7 @@ def roofline_probe(device, batch: int, launches: int):
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         b3w = CV.B3_WINO
         kname = "conv_b3_wino2d_kernel" if b3w else "conv_b3_kernel"
-        traffic, traffic_note = _pmc_traffic(kname, "r05_pmc_b3w" if b3w else "r05_pmc_b3") if batch == 32 else (None, None)
+        traffic, traffic_note = _pmc_traffic(kname, "pmc_b3w" if b3w else "pmc_b3") if batch == 32 else (None, None)
         executed = achieved * (4.0 if b3w else 6.0)       # bf16 MFMA FLOPs issued per algorithmic f32 FLOP
         return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -165,7 +165,7 @@ def roofline_probe(device, batch: int, launches: int):
                 "executed_bf16_tflops": round(executed, 1), "mfma_executed_frac": round(executed / PEAK_BF16_MFMA_TFLOPS, 4),
                 "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)}
     wino = CV.WINOGRAD
-    traffic, traffic_note = _pmc_traffic("wino", "r02_pmc_f32") if (wino and batch == 32) else (None, None)
+    traffic, traffic_note = _pmc_traffic_of("wino", "r02_pmc_f32") if (wino and batch == 32) else (None, None)
     kernel = ("conv3x3_wino_kernel<true,false> (1-D Winograd F(2,3); executes 2/3 of the algorithmic multiplies)" if wino
               else "conv_igemm_kernel<2,2,2,2,true,false,true> (direct implicit GEMM)")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -214,7 +214,7 @@ def roofline_probe_wgrad(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and (bf16 or CV.MATH == _lib.F32_B3):
-        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "r05_pmc_bf16wg" if bf16 else "r05_pmc_b3wg")
+        traffic, note = _pmc_traffic("conv_bf16_wgrad3_kernel" if bf16 else "conv_b3_wgrad3_kernel", "pmc_bf16wg" if bf16 else "pmc_b3wg")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on the weight gradient of G.layers.7.conv2: 128->128 @256x256, B=%d, column strips x row ranges in "
             "XCD-banded order (csrc/common.hpp)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
@@ -244,7 +244,7 @@ def roofline_probe_hbm(device, batch: int, launches: int, bf16: bool):
     ms = e0.elapsed_time(e1) / launches
     nbytes = (batch * 128 * 256 * 256 + batch * 128 * 257 * 257) * (2 if bf16 else 4)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "r05_pmc_blurbf16" if bf16 else "r05_pmc_blurf32", smallest_grid=True) if batch == 32 else (None, None)
+    traffic, note = _pmc_traffic("blur4_bf16x8_c2" if bf16 else "blur4_f32_c2", "pmc_blurbf16" if bf16 else "pmc_blurf32", smallest_grid=True) if batch == 32 else (None, None)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
             "traffic_source": note,
             "kernel": ("blur4_bf16x8_c2<0>" if bf16 else "blur4_f32_c2<0>") + " (4x4 FIR of a downsampling ConvLayer, two output columns per thread) on "
@@ -298,7 +298,7 @@ def roofline_probe_direct(device, batch: int, launches: int, bf16: bool):
     elem = 2 if bf16 else 4
     traffic = note = None
     if batch == 32 and not bf16 and CV.MATH == _lib.F32_B3:
-        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "r05_pmc_b3tp")
+        traffic, note = _pmc_traffic("conv_b3_tphase_kernel", "pmc_b3tp")
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": note, "kernel": kern + " on G.layers.7.conv1: stride-2 transposed 3x3 modconv 256->128, 128x128 -> 257x257, B=%d "
             "(all output-parity phases of the layer)" % batch, "flop_per_launch": flops, "ms_per_launch": round(ms, 4),
@@ -341,7 +341,7 @@ def roofline_probe_s2(device, batch: int, launches: int):
     finally:
         conv_plan.cache_end()
     tf = lambda ms: round(flops / (ms * 1e-3) / 1e12, 2)
-    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false,", "r05_pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
+    traffic, note = _pmc_traffic("conv_b3_s2fir_kernel<4, 4, 1, false,", "pmc_b3s2") if batch == 32 else (None, None)    # (not the side-output variant)
     alg = float(B3 * (256 * 256 + 128 * 128) * 128 * 4)
     return {"bound": "mfma", "achieved": tf(ms_f), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf(ms_f) / peak, 4), "traffic": traffic,
             "traffic_source": note,
@@ -384,7 +384,21 @@ def _src_sha(files):
     return h.hexdigest()[:16]
 
 
-def _pmc_traffic(kernel_substr: str, prefix: str, smallest_grid: bool = False):
+PMC_ROUNDS = ("r06", "r05")      # newest committed PMC set first; a set is used only while its sidecar hash matches the kernel sources
+
+
+def _pmc_traffic(kernel_substr: str, name: str, smallest_grid: bool = False):
+    """`name` = "pmc_<set>": the first round of PMC_ROUNDS whose profiles/<round>_pmc_<set>_* passes are current (see _pmc_traffic_of)."""
+    note = None
+    for rnd in PMC_ROUNDS:
+        t, n_ = _pmc_traffic_of(kernel_substr, rnd + "_" + name, smallest_grid)
+        if t is not None:
+            return t, n_
+        note = note or n_
+    return None, note
+
+
+def _pmc_traffic_of(kernel_substr: str, prefix: str, smallest_grid: bool = False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/<prefix>_*.csv;
     the counters cannot be read from inside this process): 2 x FETCH_SIZE (gfx950 reports half the bytes of a wide
     coalesced read, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, both in KB.  The passes carry a sidecar
