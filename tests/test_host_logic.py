@@ -470,12 +470,16 @@ def test_bench_evidence_readers_drop_stale_files(tmp_path, monkeypatch):
             for g_, n_, v_ in rows:
                 w.writerow([g_, n_, cname, v_ * mul])
     kb = lambda fetch, write: int((2 * fetch + write) * 1024)
-    assert bench._pmc_traffic("k<4, 4, 1, false>", "rX_pmc_k")[0] == kb(500.0, 250.0)                       # both grids of that instantiation
-    assert bench._pmc_traffic("k<4, 4, 1, false>", "rX_pmc_k", smallest_grid=True)[0] == kb(100.0, 50.0)    # the entry's own launch
-    assert bench._pmc_traffic("k<4, 4, 1, true>", "rX_pmc_k")[0] == kb(400.0, 200.0)
+    assert bench._pmc_traffic_of("k<4, 4, 1, false>", "rX_pmc_k")[0] == kb(500.0, 250.0)                    # both grids of that instantiation
+    assert bench._pmc_traffic_of("k<4, 4, 1, false>", "rX_pmc_k", smallest_grid=True)[0] == kb(100.0, 50.0) # the entry's own launch
+    assert bench._pmc_traffic_of("k<4, 4, 1, true>", "rX_pmc_k")[0] == kb(400.0, 200.0)
+    # the newest round whose passes are current wins (round 6: PMC_ROUNDS); a round without files is skipped
+    monkeypatch.setattr(bench, "PMC_ROUNDS", ("rY", "rX"))
+    assert bench._pmc_traffic("k<4, 4, 1, false>", "pmc_k")[0] == kb(500.0, 250.0)
     (tmp_path / "ideas_amd" / "csrc" / "k.hip").write_text("kernel v2")                                     # the kernel changed: stale
-    val, note = bench._pmc_traffic("k<4, 4, 1, false>", "rX_pmc_k")
+    val, note = bench._pmc_traffic_of("k<4, 4, 1, false>", "rX_pmc_k")
     assert val is None and "stale" in note
+    assert bench._pmc_traffic("k<4, 4, 1, false>", "pmc_k")[0] is None
 
     # eager comparator files: full (default find mode) preferred over fast; any sidecar mismatch drops the file
     for f in ("oracle/torch_ref.py", "tests/eager_baseline.py"):
@@ -493,6 +497,8 @@ def test_bench_evidence_readers_drop_stale_files(tmp_path, monkeypatch):
     assert bench.eager_complete(argparse.Namespace(batch=16)) is None                                        # another batch
     (prof / "r04_eager_full.json").write_text(json.dumps(dict(side, eager_gpu_images_per_sec=18.0, torch_version="0.0")))
     assert bench.eager_complete(a)["file"] == "profiles/r04_eager_fast.json"                                 # stale full -> the fast one
+    (prof / "r06_eager_full.json").write_text(json.dumps(dict(side, eager_gpu_images_per_sec=18.1)))         # the newest measurement first
+    assert bench.eager_complete(a)["file"] == "profiles/r06_eager_full.json"
     (tmp_path / "oracle" / "torch_ref.py").write_text("the comparator's step changed")
     assert bench.eager_complete(a) is None
 
