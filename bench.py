@@ -720,7 +720,11 @@ def main():
     if world > 1 or forced:
         backend = os.environ.get("IDEAS_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+            # NO device_id: binding the group to the device makes ProcessGroupNCCL create its communicator eagerly, and on this stack
+            # (torch 2.10 + RCCL 2.26) every later iteration is then 13.5 ms slower WITHOUT a single collective being issued (f32 393.3 ->
+            # 406.9 ms, same box; tools/probes/pg_init_overhead.py, profiles/r06_pg_init_overhead.txt); the lazily created communicator
+            # (first collective on the current device, which set_device fixed above) costs nothing (392.9 ms)
+            dist.init_process_group(backend="nccl", init_method="env://")
         else:
             dist.init_process_group(backend=backend, init_method="env://")
 
@@ -828,6 +832,14 @@ def roofline_weighted(run_iteration, bf16: bool):
             "families": [r for r in rows if r["ms"] >= 0.5]}
 
 
+def _barrier(device):
+    """dist.barrier() on THIS rank's device (the group is not bound to one: see the init_process_group call)."""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[device.index])
+    else:
+        dist.barrier()
+
+
 def run_steps(a, precision_name, steps, warmup, device, world, rank):
     """Build the trainer in `precision_name`, run `warmup` untimed and exactly `steps` timed iterations between
     barrier + synchronize pairs; returns the max-over-ranks wall time and what the line needs.  Frees everything on return."""
@@ -863,7 +875,7 @@ def run_steps(a, precision_name, steps, warmup, device, world, rank):
     for j in range(warmup):
         step(args.d_reg_every * 1000 + j)          # first warm-up iteration exercises the R1 branch
     if dist_on:
-        dist.barrier()
+        _barrier(device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(1, steps + 1):
@@ -871,7 +883,7 @@ def run_steps(a, precision_name, steps, warmup, device, world, rank):
     torch.cuda.synchronize()
     t_own = time.perf_counter() - t0               # this rank's own K steps (before it waits for the slowest rank)
     if dist_on:
-        dist.barrier()
+        _barrier(device)
     dt = time.perf_counter() - t0
     ranks_seen = None
     if dist_on:

@@ -29,7 +29,7 @@ def main():
     assert os.environ.get("IDEAS_DDP_FORCE_COLLECTIVE") == "1"
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+    dist.init_process_group(backend="nccl", init_method="env://")      # as bench.py / train.py: no device_id (communicator created lazily)
     assert dist.get_world_size() == 1
     from ideas_amd import ddp, precision, train_step as TS
     from ideas_amd.ddp import GradReducer, broadcast_parameters
@@ -137,7 +137,7 @@ def main():
     for k in range(3):
         check(run(True, noisy=True), "reducer, busy device, repetition %d" % k)
     torch.cuda.synchronize()
-    dist.barrier()
+    dist.barrier(device_ids=[0])
     dist.destroy_process_group()
     print("one-rank RCCL ok: 7 all-reduces per two iterations; vs reducer-less run: first-step gradient %.2e (run-to-run %.2e), later steps %.2e (%.2e), "
           "final parameters max |diff| %.2e (%.2e), mean %.2e (%.2e)" % (got[0], noise[0], got[1], noise[1], got[2], noise[2], got[3], noise[3]), flush=True)

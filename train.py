@@ -75,7 +75,11 @@ def main():
     if world > 1:
         backend = os.environ.get("IDEAS_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+            # NO device_id: binding the group to the device makes ProcessGroupNCCL create its communicator eagerly, and on this stack
+            # (torch 2.10 + RCCL 2.26) every later iteration is then 13.5 ms slower WITHOUT a single collective being issued (f32 393.3 ->
+            # 406.9 ms, same box; tools/probes/pg_init_overhead.py, profiles/r06_pg_init_overhead.txt); the lazily created communicator
+            # (first collective on the current device, which set_device fixed above) costs nothing (392.9 ms)
+            dist.init_process_group(backend="nccl", init_method="env://")
         else:
             dist.init_process_group(backend=backend, init_method="env://")
 
@@ -176,7 +180,10 @@ def main():
             checkpoint.save(f"{ckpt_dir}/{iter_idx}.pt", trainer, args, iter_idx)   # the reference's file name
 
     if world > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
         dist.destroy_process_group()
 
 
