@@ -910,7 +910,7 @@ def run_steps(a, precision_name, steps, warmup, device, world, rank):
     # an R1 iteration is measured right here (two R1 and two plain iterations, each between synchronisations) so that the line can
     # state the rate at exactly one R1 iteration in sixteen next to the measured one.
     r1w = None
-    if not dist_on:
+    if not dist_on and getattr(a, "roofline", "off") != "off":          # (--roofline off: A/B and profiling runs time their window and nothing else)
         def timed(idx):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
