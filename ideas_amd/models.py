@@ -28,6 +28,7 @@ from .precision import to_act, to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
 FUSE_RESIDUAL_ADDS = True     # big residual blocks: block input forked by one autograd node (gradient sum / merge add ride in kernels)
+_DCO_MERGE_FAKE_REAL = os.environ.get("IDEAS_DCO_MERGE_FR", "1") != "0"     # (A/B switch of round 6, see CooccurenceDiscriminator.forward_pair)
 FUSE_BLUR_CONV = os.environ.get("IDEAS_BLUR_CONV", "1") != "0"   # downsampling ResBlock body with conv2's Blur inside its conv kernel
 FUSE_BLUR_BACKWARD = True     # ResBlock: conv1 + conv2's Blur as one Function whose backward is one kernel (A/B switch for tools / tests)
 
@@ -427,10 +428,18 @@ class CooccurenceDiscriminator(nn.Module):
 
     def forward_pair(self, fake, real, reference, ref_batch):
         """``(forward(fake, reference, ref_batch)[0], forward(real, ref_input=...)[0], ref_input)`` -- the two calls of the D phase
-        (train.py:88-90) -- with one pass of the linear head over both (the encoder runs per batch, see encode_many)."""
-        out_f, out_r, ref = self.encode_many(fake, real, reference)
-        ref_input = self._ref_mean(ref, ref_batch)
-        both = torch.flatten(torch.cat((torch.cat((out_f, out_r), 0), torch.cat((ref_input, ref_input), 0)), 1), 1)
+        (train.py:88-90) -- with ONE encoder pass over the fake and the real patches (neither needs an input gradient there: 8B + 8B
+        samples in one launch per layer instead of two half-empty ones; the 32B reference patches keep their own pass, whose weight
+        gradients overlap this one's forward) and one pass of the linear head over both."""
+        if _DCO_MERGE_FAKE_REAL and not fake.requires_grad and not real.requires_grad and fake.shape[1:] == real.shape[1:]:
+            out_fr = self.encoder(torch.cat((fake, real), 0))
+            (ref,) = self.encode_many(reference)
+            ref_input = self._ref_mean(ref, ref_batch)
+            both = torch.flatten(torch.cat((out_fr, torch.cat((ref_input, ref_input), 0)), 1), 1)
+        else:
+            out_f, out_r, ref = self.encode_many(fake, real, reference)
+            ref_input = self._ref_mean(ref, ref_batch)
+            both = torch.flatten(torch.cat((torch.cat((out_f, out_r), 0), torch.cat((ref_input, ref_input), 0)), 1), 1)
         pred = self.linear(both)
         return pred[:fake.shape[0]], pred[fake.shape[0]:], ref_input
 
