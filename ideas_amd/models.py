@@ -28,7 +28,6 @@ from .precision import to_act, to_f32
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
 FUSE_RESIDUAL_ADDS = True     # big residual blocks: block input forked by one autograd node (gradient sum / merge add ride in kernels)
-_DCO_MERGE_FAKE_REAL = os.environ.get("IDEAS_DCO_MERGE_FR", "1") != "0"     # (A/B switch of round 6, see CooccurenceDiscriminator.forward_pair)
 FUSE_BLUR_CONV = os.environ.get("IDEAS_BLUR_CONV", "1") != "0"   # downsampling ResBlock body with conv2's Blur inside its conv kernel
 FUSE_BLUR_BACKWARD = True     # ResBlock: conv1 + conv2's Blur as one Function whose backward is one kernel (A/B switch for tools / tests)
 
@@ -407,9 +406,8 @@ class CooccurenceDiscriminator(nn.Module):
         )
 
     def encode_many(self, *batches):
-        """One encoder pass per patch batch.  (ONE pass over the concatenated batches was measured in round 3 -- f32 450.8 -> 454.5 ms,
-        bf16 162.3 -> 161.7 ms: the 32B-patch pass already fills the chip and the merged pass loses the overlap of one pass's
-        weight gradients with the next pass's forward -- and removed in round 6.)"""
+        """One encoder pass per patch batch (the G phase and R1: one batch needs an input gradient, the other does not; the D phase
+        merges its batches in forward_pair)."""
         return tuple(self.encoder(b) for b in batches)
 
     @staticmethod
@@ -428,20 +426,28 @@ class CooccurenceDiscriminator(nn.Module):
 
     def forward_pair(self, fake, real, reference, ref_batch):
         """``(forward(fake, reference, ref_batch)[0], forward(real, ref_input=...)[0], ref_input)`` -- the two calls of the D phase
-        (train.py:88-90) -- with ONE encoder pass over the fake and the real patches (neither needs an input gradient there: 8B + 8B
-        samples in one launch per layer instead of two half-empty ones; the 32B reference patches keep their own pass, whose weight
-        gradients overlap this one's forward) and one pass of the linear head over both."""
-        if _DCO_MERGE_FAKE_REAL and not fake.requires_grad and not real.requires_grad and fake.shape[1:] == real.shape[1:]:
+        (train.py:88-90) -- with ONE encoder pass over the fake, the real and the reference patches (8B + 8B + 32B samples: the encoder
+        has no cross-sample op, so every sample's features are those of a separate pass) and one pass of the linear head.  In the D
+        phase no patch batch needs an input gradient, so nothing is computed that three passes would not compute; what changes is the
+        launch size: the 8B-sample passes ran their layers at 0.69 of the 32B pass's per-sample rate (tools/probes/dco_census.py).
+        Same box, two interleaved runs (profiles/r06_dco_merge_ab.txt, r06_dco_merge3_ab.txt): three passes 400.1 ms, fake + real
+        merged 397.8 / 395.8, all three merged 394.5; bf16 150.5 / 148.7 / 147.0.  (Round 3 measured the full merge 0.8 % SLOWER in
+        f32 -- on that round's kernels; IDEAS_DCO_MERGE=0 / 1 restore three passes / the fake + real merge for A/B runs.)"""
+        mode = os.environ.get("IDEAS_DCO_MERGE", "2")
+        plain = not fake.requires_grad and not real.requires_grad and not reference.requires_grad and fake.shape[1:] == real.shape[1:] == reference.shape[1:]
+        nf, nr = fake.shape[0], real.shape[0]
+        if plain and mode == "2":
+            out = self.encoder(torch.cat((fake, real, reference), 0))
+            out_fr, ref = out[:nf + nr], out[nf + nr:]
+        elif plain and mode == "1":
             out_fr = self.encoder(torch.cat((fake, real), 0))
             (ref,) = self.encode_many(reference)
-            ref_input = self._ref_mean(ref, ref_batch)
-            both = torch.flatten(torch.cat((out_fr, torch.cat((ref_input, ref_input), 0)), 1), 1)
         else:
             out_f, out_r, ref = self.encode_many(fake, real, reference)
-            ref_input = self._ref_mean(ref, ref_batch)
-            both = torch.flatten(torch.cat((torch.cat((out_f, out_r), 0), torch.cat((ref_input, ref_input), 0)), 1), 1)
-        pred = self.linear(both)
-        return pred[:fake.shape[0]], pred[fake.shape[0]:], ref_input
+            out_fr = torch.cat((out_f, out_r), 0)
+        ref_input = self._ref_mean(ref, ref_batch)
+        pred = self.linear(torch.flatten(torch.cat((out_fr, torch.cat((ref_input, ref_input), 0)), 1), 1))
+        return pred[:nf], pred[nf:], ref_input
 
 
 class DistributionDiscriminator(nn.Module):

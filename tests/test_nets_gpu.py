@@ -113,7 +113,7 @@ def test_cooccurrence_discriminator_forward_pair(nets_golden):
         g1 = torch.autograd.grad((a1 * 1.5).sum() - b1.sum(), [fake] + params)
         for u, v in zip(g1, g0):
             assert rel_err(u, v) < 1e-4
-    # the D phase's form: neither patch batch needs an input gradient -> fake and real share ONE encoder pass (round 6)
+    # the D phase's form: no patch batch needs an input gradient -> fake, real and reference patches share ONE encoder pass (round 6)
     fd = fake.detach()
     a2, b2, r2 = net.forward_pair(fd, real, ref, 2)
     assert rel_err(a2, a0) < 1e-5 and rel_err(b2, b0) < 1e-5 and rel_err(r2, r0) < 1e-5
