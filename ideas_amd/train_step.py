@@ -40,6 +40,11 @@ NET_CLASSES = {
     "Dreal": "ImageLevelDiscriminator", "Dco": "CooccurenceDiscriminator", "Ddist": "DistributionDiscriminator",
 }
 import os as _os
+# The G phase's two generator passes on the sampled structure code, G(S2, T1) and G(S2, T2) (train.py:155-160), as ONE pass over 2B samples
+# (per-sample styles, no cross-sample op: the same values): the 16x16 / 32x32 stages fill the chip twice as well, forward and backward.  Same
+# box, two interleaved runs (profiles/r06_g_pair_ab.txt): 395.6 -> 393.5 ms f32, 147.2 -> 146.4 bf16; pairing the D phase's two no-grad
+# passes as well changes nothing ("d": 395.7 / 147.5).  IDEAS_G_PAIR=x: separate passes (A/B); "dg": both phases.
+_G_PAIR = _os.environ.get("IDEAS_G_PAIR", "g")
 DEFER_SINK_JOIN = _os.environ.get("IDEAS_DEFER_SINK_JOIN", "1") != "0"     # A/B switch (see op/conv.py::grad_sink)
 EMA_NETS = ("E", "G", "Gstru", "Ex")
 G_SIDE = ("E", "G", "Gstru")
@@ -290,8 +295,11 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
         T2 = draws.T2_d
         if not share:
             hat_X1 = T["G"](S1, T1)
-        hat_X2 = T["G"](S2, T1)
-        hat_X3 = T["G"](S2, T2)
+        if _G_PAIR in ("d", "dg"):       # (A/B only: no gain measured for the no-grad pair)
+            hat_X2, hat_X3 = T["G"](torch.cat((S2, S2), 0), torch.cat((T1, T2), 0)).chunk(2, 0)
+        else:
+            hat_X2 = T["G"](S2, T1)
+            hat_X3 = T["G"](S2, T2)
     fake_pred = T["Dreal"](torch.cat((hat_X1, hat_X2, hat_X3), 0))
     real_pred = T["Dreal"](X)
     losses["D_real_loss"] = d_logistic_loss(real_pred, fake_pred)
@@ -358,8 +366,11 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     T2 = draws.T2_g
     if shared is None:
         hat_X1 = T["G"](S1, T1)
-    hat_X2 = T["G"](S2, T1)
-    hat_X3 = T["G"](S2, T2)
+    if _G_PAIR in ("g", "dg"):
+        hat_X2, hat_X3 = T["G"](torch.cat((S2, S2), 0), torch.cat((T1, T2), 0)).chunk(2, 0)
+    else:
+        hat_X2 = T["G"](S2, T1)
+        hat_X3 = T["G"](S2, T2)
     losses["G_rec_loss"] = F.l1_loss(hat_X1, X)
     if d_step is not None:
         d_step.finish()          # discriminators from here on: the reference's order (D step before the G phase, train.py:101-145)
