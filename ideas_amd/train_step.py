@@ -366,7 +366,9 @@ def _train_iteration(trainer, args, X: torch.Tensor, iter_idx: int, draws: Optio
     T2 = draws.T2_g
     if shared is None:
         hat_X1 = T["G"](S1, T1)
-    if _G_PAIR in ("g", "dg"):
+    if _G_PAIR in ("g", "dg") and args.elide_second_backward:
+        # (not with the reference's literal second backward: its re-traversal from Loss_Ex reaches G through the container image alone
+        #  and would drag the other half of a paired pass along -- 481.6 -> 500.7 ms on that side configuration)
         hat_X2, hat_X3 = T["G"](torch.cat((S2, S2), 0), torch.cat((T1, T2), 0)).chunk(2, 0)
     else:
         hat_X2 = T["G"](S2, T1)

@@ -70,4 +70,8 @@ def dc():
     b, _ = nets["Dco"](fake, ref_input=ri)
     (a.sum() + b.sum()).backward()
 CUR["net"] = "Dco"
-timeit("Dco fwd+bwd, 8B + 8B patches, 32B references", dc, 3 * 1.0 * (8 + 8 + 32) * B)
+timeit("Dco fwd+bwd, 8B + 8B patches, 32B references (three encoder passes)", dc, 3 * 1.0 * (8 + 8 + 32) * B)
+def dc1():      # as the D phase runs it since round 6: one encoder pass over all 48B patches (CooccurenceDiscriminator.forward_pair)
+    a, b, _ = nets["Dco"].forward_pair(fake, fake, ref, 4)
+    (a.sum() + b.sum()).backward()
+timeit("Dco fwd+bwd, 8B + 8B + 32B patches in ONE encoder pass (the D phase)", dc1, 3 * 1.0 * (8 + 8 + 32) * B)
