@@ -27,11 +27,11 @@ for tag, kern in KERNEL.items():
     pre = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{'b3w' if tag == 'f32' else 'bf16'}")
     shutil.copy(os.path.join(src, tag + "_bench_default.json"), os.path.join(ROOT, "profiles", f"{rnd}_{tag}_bench_default.json"))
     for what in ("roofline", "step"):
-        f = glob.glob(os.path.join(src, f"{tag}_{what}", "**", "*kernel_stats.csv"), recursive=True)
-        if f:
+        f = sorted(glob.glob(os.path.join(src, f"{tag}_{what}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+        if f:      # (newest first: gpurun merges the output directories of successive runs)
             shutil.copy(f[0], os.path.join(ROOT, "profiles", f"{rnd}_{tag}_{what}_kernel_stats.csv"))
     for cset, short in NAMES.items():
-        f = glob.glob(os.path.join(src, f"{tag}_pmc_{cset}", "**", "*counter_collection.csv"), recursive=True)
+        f = sorted(glob.glob(os.path.join(src, f"{tag}_pmc_{cset}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
         if not f:
             continue
         rows = list(csv.DictReader(open(f[0])))
