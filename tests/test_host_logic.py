@@ -122,10 +122,12 @@ def test_product_step_logic_against_reference_train(which):
     check_replay(g, meta, trainer, out, log)
 
 
-def test_literal_second_backward_gives_same_ex_gradient():
+def test_literal_second_backward_gives_same_ex_gradient(monkeypatch):
     """elide_second_backward=True takes Ex's gradient over the Ex sub-graph only; the reference's literal
-    second traversal (train.py:214-215) must give the same Ex update."""
+    second traversal (train.py:214-215) must give the same Ex update.  (The G phase's paired generator pass of round 6 is taken
+    with the elided backward only; it is switched off here so that both runs evaluate the same forward, bit for bit.)"""
     from ideas_amd import train_step as TS
+    monkeypatch.setattr(TS, "_G_PAIR", "x")
     from ideas_amd.models import init_model
     from test_nets_gpu import ZeroDco
     res = []
